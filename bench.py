@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — events/sec through divide_rounds + decide_fame (BASELINE.json metric).
+
+One "step" = one pass of the hot path (sw_divide_rounds + sw_decide_fame through the
+C-ABI) over one synthetic hashgraph whose events are ALREADY resident in HBM
+(sw_append_events is ingest, mirrors Node.add_event, and is outside the timed region).
+Workload at N=1: BASELINE.json configs[2] — 256 members, 1M events, uniform gossip
+(SURVEY.md §8d generator), seed 3.  With --gpus N every rank runs an independent replica
+of that workload (different seed): the path does not shard across GPUs (DESIGN.md §(e),
+"replicas only"), so scaling is weak and there is no data-path collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def algorithmic_bytes(n, counters, n_events):
+    """divide_rounds 12n + n^2/8 + 24 per non-root event;
+    decide_fame V*(4n + n^2/8) + P2*n/8."""
+    dr = (n_events - n) * (12 * n + n * n // 8 + 24)
+    df = counters["voter_evals"] * (4 * n + n * n // 8) + counters["majority_evals"] * (n // 8)
+    return dr, df
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--members", type=int, default=256)
+    ap.add_argument("--events", type=int, default=1_000_000)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=150_000,
+                    help="events of the same stream timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--contexts", type=int, default=4, help="max resident replicas of the DAG per GPU")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("py-swirld_amd")
+    n, N = args.members, args.events
+    stream = pkg.synth_hashgraph(n, N, args.seed + rank)  # generator: host, untimed
+    n_ctx = max(1, min(args.contexts, args.steps + args.warmup))
+    ctxs = []
+    t_ing0 = time.perf_counter()
+    for _ in range(n_ctx):
+        h = pkg.Hashgraph(n, device=local_rank)
+        h.reserve(N)
+        h.append_events(*stream)  # ingest (Node.add_event): untimed
+        ctxs.append(h)
+    ingest_s = (time.perf_counter() - t_ing0) / n_ctx
+
+    def one_step(i):
+        h = ctxs[i % n_ctx]
+        if i >= n_ctx:
+            h.rewind()
+        h.divide_rounds(0, N)
+        return h.decide_fame()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        new_c = one_step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * N * args.steps / dt
+
+    # ---- roofline of the dominant kernel (k_tally_candidates), one extra profiled pass ----
+    h = ctxs[0]
+    h.rewind()
+    h.set_profiling(True)
+    c0 = h.counters()
+    h.divide_rounds(0, N)
+    tm_dr = h.timings()
+    h.decide_fame()
+    tm = h.timings()
+    c1 = h.counters()
+    h.set_profiling(False)
+    evals = c1["tally_evals"] - c0["tally_evals"]
+    launches = max(1, tm_dr["tally_launches"])
+    bytes_per_eval = 4 * n + n * n // 8 + 8  # one can_see row + n gathered n-bit masks + result
+    avg_launch_ms = tm_dr["tally_ms"] / launches
+    achieved = (evals / launches) * bytes_per_eval / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("tally_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    cdelta = {k: c1[k] - c0[k] for k in c1}
+    dr_b, df_b = algorithmic_bytes(n, cdelta, N)
+    roofline = {
+        "bound": "hbm", "kernel": "k_tally_candidates", "achieved": round(achieved, 2), "peak": 8000.0,
+        "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+        "avg_launch_us": round(avg_launch_ms * 1e3, 2), "launches": launches,
+        "evals_per_launch": round(evals / launches, 1), "bytes_per_eval": bytes_per_eval,
+        "path_algorithmic_GBps": round((dr_b + df_b) / (ms_per_step * 1e-3) / 1e9, 2),
+        "phase_ms": {k: round(v, 3) for k, v in (("can_see", tm_dr["can_see_ms"]), ("rounds", tm_dr["rounds_ms"]),
+                                                 ("tally", tm_dr["tally_ms"]), ("finalize", tm_dr["finalize_ms"]),
+                                                 ("fame", tm["fame_ms"]))},
+    }
+
+    # ---- CPU baseline: the oracle (C port of the reference algorithm), 1 core, bounded sample ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle.oracle import Oracle
+        M = min(args.cpu_sample, N)
+        o = Oracle(n)
+        o.append_events(*[a[:M] for a in stream])
+        tc0 = time.perf_counter()
+        o.divide_rounds(0, M)
+        o.decide_fame()
+        tc = time.perf_counter() - tc0
+        cpu_baseline = {"value": round(M / tc, 1), "unit": "events/s", "cores": 1, "kind": "port",
+                        "host_cores": os.cpu_count(),
+                        "sample": "first %d events of the same stream through oracle/swirld_oracle.c "
+                                  "(sequential C restatement of swirld.py:187-277), %.1f s" % (M, tc)}
+
+    if rank == 0:
+        out = {
+            "metric": "events/sec through divide_rounds+decide_fame", "value": round(value, 1),
+            "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%d members, %d events, uniform-gossip hashgraph, one batch "
+                                   "divide_rounds + decide_fame per step" % (n, N),
+                       "members": n, "events": N, "seed": args.seed,
+                       "parallelism": "replicas x%d (no data-path collective)" % world,
+                       "rounds": c1["rounds"], "ingest_s_untimed": round(ingest_s, 3),
+                       "new_c_last_step": int(len(new_c))},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

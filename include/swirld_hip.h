@@ -1,0 +1,175 @@
+/*
+ * swirld_hip.h — C-ABI of the MI355X-native virtual-voting hot path of py-swirld.
+ *
+ * The reference (Lapin0t/py-swirld) has no FFI or plugin interface: its hot path
+ * is three methods of one Python class, `Node` (swirld.py:36-328).  This header is
+ * therefore the boundary a maintainer would bind with ctypes from inside `Node`
+ * (see INTEGRATION.md); each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - plain C types only; the caller owns every buffer (typically numpy arrays);
+ *  - every function returns SW_OK (0) or a negative errno-style code and never
+ *    throws; sw_last_error() gives a human-readable message for the last failure;
+ *  - one context per Node view; a context is NOT thread-safe (the reference is
+ *    single-threaded by design, README.md:27-28, swirld.py:152); independent
+ *    contexts may live on different devices/streams;
+ *  - events are addressed by DENSE INDEX = the order in which they were appended,
+ *    which must be a topological order (parents before children), exactly the
+ *    order `Node.add_event` is called in (swirld.py:114-120, 133-144); members are
+ *    addressed by dense index 0..n-1 (the host glue keeps pk -> index);
+ *  - "absent" event / parent / witness is -1.
+ */
+#ifndef SWIRLD_HIP_H
+#define SWIRLD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_OK          0
+#define SW_EIO        (-5)   /* HIP runtime error (message in sw_last_error)            */
+#define SW_ENOMEM     (-12)
+#define SW_ENODEV     (-19)  /* no usable GPU / device index out of range               */
+#define SW_EINVAL     (-22)
+#define SW_ERANGE     (-34)  /* index / round range outside the stored hashgraph        */
+#define SW_EOVERFLOW  (-75)  /* total stake too large for the 32-bit tally              */
+#define SW_ENOTSUP    (-95)  /* input outside the supported domain (e.g. forked DAG)    */
+
+#define SW_MAX_MEMBERS 1024
+
+typedef struct sw_ctx sw_ctx;
+
+/* ABI version of this header (bumped on any signature change). */
+int sw_version(void);
+
+/*
+ * Context = the voting state of one Node (swirld.py:38-72): `stake`, `tot_stake`,
+ * `min_s` (handled as the exact integer tests 3x > 2T and 2x > T, Appendix A Q1),
+ * module constant C = coin_period (swirld.py:17).
+ * device = HIP device ordinal.  Fails with SW_ENODEV when no GPU is present: there
+ * is no CPU fallback in this library.
+ */
+int sw_create(int n_members, const uint64_t* stake, int coin_period, int device, sw_ctx** out);
+int sw_destroy(sw_ctx* ctx);
+const char* sw_last_error(const sw_ctx* ctx);   /* ctx may be NULL: last create() error */
+
+/* Pre-size device storage for n_events events (optional; append grows on demand). */
+int sw_reserve(sw_ctx* ctx, int64_t n_events);
+
+/*
+ * Mirror of Node.add_event (swirld.py:114-120) for K events in topological order:
+ * stores creator / parents, computes `height` (0 for roots, 1+max(parent heights)).
+ * self_parent/other_parent are dense indices (both -1 for a root, swirld.py:85-87).
+ * t = Event.t (float64 timestamp), sig64 = Event.s (64-byte signature; its first
+ * byte's top bit is the coin bit of swirld.py:272, all 64 bytes feed the whitening
+ * of swirld.py:281-285).  t and sig64 may be NULL (zeros are stored).
+ * Validation mirrors is_valid_event's structural half (swirld.py:104-108): parents
+ * must exist, self-parent must be by the same creator, other-parent by another.
+ * A fork (two children of one self-parent, or a second root of one member) is
+ * accepted and recorded; the round-synchronous bulk path then refuses it
+ * (SW_ENOTSUP, fork behaviour is unspecified in the reference, README.md:84).
+ */
+int sw_append_events(sw_ctx* ctx, int64_t K, const int32_t* creator, const int32_t* self_parent,
+                     const int32_t* other_parent, const double* t, const uint8_t* sig64);
+int64_t sw_num_events(const sw_ctx* ctx);
+
+/*
+ * Node.divide_rounds(events) (swirld.py:187-222) for the K events [first, first+K):
+ * fills can_see rows, round numbers and the witness table.  `first` must equal the
+ * number of events already divided (the reference processes every new event exactly
+ * once, in order: swirld.py:325).
+ */
+int sw_divide_rounds(sw_ctx* ctx, int64_t first, int64_t K);
+
+/*
+ * Node.decide_fame() (swirld.py:224-277).  Writes the newly decided rounds (`new_c`,
+ * swirld.py:274-277) in ascending order to new_rounds[0..*n_new) and adds them to
+ * the consensus set.  cap = capacity of new_rounds; SW_ERANGE if too small (state is
+ * still updated, *n_new holds the required size).
+ */
+int sw_decide_fame(sw_ctx* ctx, int32_t* new_rounds, int cap, int* n_new);
+
+/*
+ * Node.find_order(new_c) (swirld.py:280-311) for the given rounds (processed in
+ * ascending order like sorted(new_c)).  Appends to the internal `transactions` list
+ * and writes the newly ordered event indices, in final order, to out_events.
+ */
+int sw_find_order(sw_ctx* ctx, const int32_t* rounds, int n_rounds, int32_t* out_events,
+                  int64_t cap, int64_t* n_out);
+
+/* ---- getters (lazy dict views of the Node state; all copy device -> caller) ---- */
+int sw_get_height(sw_ctx* ctx, int64_t first, int64_t K, int32_t* out);          /* Node.height   */
+int sw_get_round(sw_ctx* ctx, int64_t first, int64_t K, int32_t* out);           /* Node.round    */
+/* Node.can_see rows: out[K][n_members], entry = latest event of that member seen, -1 absent */
+int sw_get_can_see(sw_ctx* ctx, int64_t first, int64_t K, int32_t* out);
+int sw_max_round(sw_ctx* ctx, int* out);                                          /* max(witnesses) */
+/* Node.witnesses[r][member] for r in [r0, r1): out[(r1-r0)][n_members]; dict order inside
+ * a round = ascending event index (registration order, swirld.py:197, 222). */
+int sw_get_witnesses(sw_ctx* ctx, int r0, int r1, int32_t* out);
+/* Node.famous for the same table: -1 undecided, 0 False, 1 True (swirld.py:263). */
+int sw_get_famous(sw_ctx* ctx, int r0, int r1, int8_t* out);
+/* Node.consensus membership for r in [r0, r1): 1 if r in consensus (swirld.py:276). */
+int sw_get_consensus(sw_ctx* ctx, int r0, int r1, uint8_t* out);
+/* Diagnostic: per event the member bitmask {c_ : round[can_see[e][c_]] == round[e]}
+ * (the inner test of swirld.py:211-214 / 250-252); out[K][ceil(n/64)] little-endian words. */
+int sw_get_sees_mask(sw_ctx* ctx, int64_t first, int64_t K, uint64_t* out);
+/* Diagnostic: Node.votes[voter][candidate] for voter = witness (rv, mv), candidate =
+ * witness (rc, mc): -1 = no entry, 0/1 = vote (swirld.py:258-272). */
+int sw_get_vote(sw_ctx* ctx, int rv, int mv, int rc, int mc, int8_t* out);
+/* Node.transactions / Node.idx: total ordered so far, and a slice of the order. */
+int sw_num_ordered(sw_ctx* ctx, int64_t* out);
+int sw_get_transactions(sw_ctx* ctx, int64_t first, int64_t K, int32_t* out);
+
+/* Exact work counters of the calls so far: used by bench.py's roofline. */
+typedef struct sw_counters {
+    int64_t events_divided;      /* events through divide_rounds                          */
+    int64_t rounds;              /* max round + 1                                          */
+    int64_t tally_evals;         /* strongly-sees tallies evaluated by the bulk round loop */
+    int64_t round_iterations;    /* bulk round-loop iterations (>= rounds)                 */
+    int64_t voter_evals;         /* V: voter tallies in decide_fame (swirld.py:247-254)    */
+    int64_t majority_evals;      /* P2: majority() evaluations, d >= 2 (swirld.py:260)     */
+    int64_t levels;              /* DAG height levels swept by the can_see kernel          */
+    int64_t kernel_launches;
+} sw_counters;
+int sw_get_counters(sw_ctx* ctx, sw_counters* out);
+
+/* Per-phase GPU time of the most recent divide_rounds / decide_fame call, measured with
+ * hipEvents on the context's own stream (ms).  Enabled by sw_set_profiling(ctx, 1). */
+typedef struct sw_timings {
+    float can_see_ms;        /* level-synchronous can_see rows                          */
+    float rounds_ms;         /* round-synchronous strongly-sees loop (all iterations)    */
+    float tally_ms;          /* ... of which: the tally kernel (dominant kernel)         */
+    int32_t tally_launches;
+    float finalize_ms;       /* round numbers, sees-masks, witness table                 */
+    float fame_ms;           /* decide_fame: voter tallies + elections                   */
+    float total_ms;
+} sw_timings;
+int sw_set_profiling(sw_ctx* ctx, int enable);
+int sw_get_timings(sw_ctx* ctx, sw_timings* out);
+
+/* Measurement utility (no reference counterpart): forget all voting state (rounds,
+ * witnesses, fame, consensus, order) as if divide_rounds had never been called; the
+ * appended events stay resident.  Lets bench.py time repeated passes over one DAG. */
+int sw_rewind(sw_ctx* ctx);
+
+/* Block until all work queued on the context's stream is complete. */
+int sw_synchronize(sw_ctx* ctx);
+
+/*
+ * Host utility (no GPU): synthetic gossip hashgraph with the DAG shape swirld.test()
+ * produces (swirld.py:323, 342-344).  Events 0..n-1 are the roots.
+ * mode 0: uniform gossip.  mode 1: two cliques, cross-clique probability p0.
+ * mode 2: a fraction p0 of members has relative activity p1.  mode 3: stale
+ * other-parents (walk back the peer's self-parent chain with probability p0 per step).
+ * t (nullable) = float(index); sig64 (nullable) = N*64 seeded random bytes.
+ */
+int sw_synth_hashgraph(int n, int64_t N, uint64_t seed, int mode, double p0, double p1,
+                       int32_t* creator, int32_t* self_parent, int32_t* other_parent,
+                       double* t, uint8_t* sig64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIRLD_HIP_H */

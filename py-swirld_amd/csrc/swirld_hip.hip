@@ -1,0 +1,836 @@
+// Host side of the C-ABI (include/swirld_hip.h): owns the HBM-resident hashgraph state of one
+// Node view and drives the kernels of kernels.hip.h on one HIP stream.
+//
+// Path (reference file:line):  Node.add_event swirld.py:114-120 -> sw_append_events;
+// Node.divide_rounds swirld.py:187-222 -> sw_divide_rounds; Node.decide_fame
+// swirld.py:224-277 -> sw_decide_fame; Node.find_order swirld.py:280-311 -> sw_find_order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/swirld_hip.h"
+#include "kernels.hip.h"
+
+namespace {
+
+std::string g_create_error;
+
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+};
+
+}  // namespace
+
+struct sw_ctx {
+    int n = 0, nw = 0, npad = 0, coin_period = 6, device = 0;
+    bool unit_stake = true;
+    uint32_t tot = 0;
+    std::vector<uint32_t> stake_h;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // host mirror of the DAG (validation, height, chains)
+    std::vector<int32_t> cr, sp, op, ht;
+    std::vector<int32_t> head;      // latest event per member (-1 none)
+    bool has_forks = false;
+    int64_t N = 0, cap = 0, divided = 0;
+    bool chains_dirty = true;
+
+    // device: events
+    DBuf<int32_t> d_cr, d_sp, d_op, d_ht, d_round, d_L, d_chain_ev;
+    DBuf<unsigned char> d_coin, d_sig;
+    DBuf<double> d_t;
+    DBuf<u64> d_S;
+    DBuf<int32_t> d_chain_start;  // npad + 1
+    DBuf<uint32_t> d_stake;       // npad
+
+    // device: levels
+    DBuf<int32_t> d_lev_cnt, d_lev_start, d_lev_cursor;
+    DBuf<int4> d_desc;
+
+    // device: rounds
+    int Rcap = 0;  // rows allocated in lo/lopos/wit/fam/cons/newc
+    int R = 0;     // max round + 1
+    DBuf<int32_t> d_lo, d_lopos, d_wit;
+    DBuf<signed char> d_fam;
+    DBuf<unsigned char> d_cons, d_newc;
+    DBuf<u64> d_Sw;
+    int Sw_rows = 0;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_cand;
+    DBuf<unsigned char> d_res;
+    DBuf<u64> d_Mb;
+    RState* d_state = nullptr;
+    FameCounters* d_fc = nullptr;
+    std::vector<int32_t> front;       // per member: max r with lo[r][c] finite (-1 none)
+    std::vector<int32_t> lo0_h;       // host copy of lo[0][.] (chain starts)
+    std::vector<unsigned char> cons_h;  // host mirror of consensus
+    int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
+
+    // tuning
+    int K = 16;        // candidates per member per tally launch
+    int MCAP = 0;      // band size (events)
+    int BATCH = 24;    // loop iterations between host checks
+
+    // profiling
+    bool profiling = false;
+    sw_timings tm{};
+    sw_counters ctr{};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<int64_t> transactions;  // reserved for find_order
+};
+
+namespace {
+
+int fail(sw_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(c, SW_EIO, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define CHK(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != SW_OK) return rc_; \
+    } while (0)
+
+// grow a device buffer to >= need elements, preserving the first `keep` elements
+template <class T>
+int dgrow(sw_ctx* c, DBuf<T>& b, size_t need, size_t keep) {
+    if (need <= b.cap) return SW_OK;
+    size_t nc = b.cap ? b.cap : 1;
+    while (nc < need) nc = nc + nc / 2 + 64;
+    if (b.cap == 0) nc = need;  // first allocation: exact (reserve() gives the final size)
+    T* q = nullptr;
+    hipError_t e = hipMalloc((void**)&q, nc * sizeof(T));
+    if (e != hipSuccess) return fail(c, SW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", nc * sizeof(T), hipGetErrorString(e));
+    if (keep && b.p) {
+        HIPCHK(c, hipMemcpyAsync(q, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = q;
+    b.cap = nc;
+    return SW_OK;
+}
+
+template <class T>
+void dfree(DBuf<T>& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int fill_i32(sw_ctx* c, int32_t* p, size_t n, int v) {
+    if (!n) return SW_OK;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill_i32, dim3(blocks), dim3(256), 0, c->stream, p, n, v);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    return SW_OK;
+}
+
+int ensure_events(sw_ctx* c, int64_t need) {
+    if (need <= c->cap) return SW_OK;
+    int64_t nc = c->cap ? c->cap : 0;
+    if (nc == 0) nc = need;
+    while (nc < need) nc = nc + nc / 2 + 1024;
+    const size_t keep = (size_t)c->N;
+    CHK(dgrow(c, c->d_cr, nc, keep));
+    CHK(dgrow(c, c->d_sp, nc, keep));
+    CHK(dgrow(c, c->d_op, nc, keep));
+    CHK(dgrow(c, c->d_ht, nc, keep));
+    CHK(dgrow(c, c->d_round, nc, keep));
+    CHK(dgrow(c, c->d_coin, nc, keep));
+    CHK(dgrow(c, c->d_t, nc, keep));
+    CHK(dgrow(c, c->d_sig, (size_t)nc * 64, keep * 64));
+    CHK(dgrow(c, c->d_S, (size_t)nc * c->nw, keep * c->nw));
+    CHK(dgrow(c, c->d_L, (size_t)nc * c->npad, keep * c->npad));
+    CHK(dgrow(c, c->d_chain_ev, nc, 0));
+    c->cap = nc;
+    return SW_OK;
+}
+
+// rows of the per-round tables; new rows are initialised (lo = INF, wit = -1, fam = -1)
+int ensure_rounds(sw_ctx* c, int need) {
+    if (need <= c->Rcap) return SW_OK;
+    int nc = c->Rcap ? c->Rcap : 256;
+    while (nc < need) nc *= 2;
+    const size_t np = c->npad;
+    const size_t keep = (size_t)c->Rcap * np;
+    CHK(dgrow(c, c->d_lo, (size_t)nc * np, keep));
+    CHK(dgrow(c, c->d_lopos, (size_t)nc * np, keep));
+    CHK(dgrow(c, c->d_wit, (size_t)nc * np, keep));
+    CHK(dgrow(c, c->d_fam, (size_t)nc * np, keep));
+    CHK(dgrow(c, c->d_cons, nc, c->Rcap));
+    CHK(dgrow(c, c->d_newc, nc, 0));
+    const size_t fresh = (size_t)(nc - c->Rcap) * np;
+    CHK(fill_i32(c, c->d_lo.p + keep, fresh, SW_INF));
+    CHK(fill_i32(c, c->d_lopos.p + keep, fresh, 0));
+    CHK(fill_i32(c, c->d_wit.p + keep, fresh, -1));
+    HIPCHK(c, hipMemsetAsync(c->d_fam.p + keep, 0xff, fresh, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cons.p + c->Rcap, 0, nc - c->Rcap, c->stream));
+    c->cons_h.resize(nc, 0);
+    c->Rcap = nc;
+    return SW_OK;
+}
+
+hipEvent_t next_event(sw_ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+struct Span {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+Span span_begin(sw_ctx* c) {
+    Span s;
+    if (c->profiling) {
+        s.a = next_event(c);
+        s.b = next_event(c);
+        if (s.a) (void)hipEventRecord(s.a, c->stream);
+    }
+    return s;
+}
+void span_end(sw_ctx* c, Span& s) {
+    if (c->profiling && s.b) (void)hipEventRecord(s.b, c->stream);
+}
+float span_ms(const Span& s) {
+    float ms = 0.f;
+    if (s.a && s.b) (void)hipEventElapsedTime(&ms, s.a, s.b);
+    return ms;
+}
+
+int rebuild_chains(sw_ctx* c) {
+    // per-member self-parent chains as CSR (counting sort by creator; index order == chain
+    // order for a fork-free DAG).
+    const int np = c->npad;
+    std::vector<int32_t> start(np + 1, 0);
+    for (int64_t e = 0; e < c->N; ++e) start[c->cr[e] + 1]++;
+    for (int m = 0; m < np; ++m) start[m + 1] += start[m];
+    std::vector<int32_t> fillp(start.begin(), start.end() - 1);
+    std::vector<int32_t> ev((size_t)c->N);
+    for (int64_t e = 0; e < c->N; ++e) ev[fillp[c->cr[e]]++] = (int32_t)e;
+    CHK(dgrow(c, c->d_chain_start, np + 1, 0));
+    HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, start.data(), (np + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (c->N)
+        HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p, ev.data(), (size_t)c->N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    c->chains_dirty = false;
+    return SW_OK;
+}
+
+template <int NW>
+int launch_cansee(sw_ctx* c, int nlev) {
+    constexpr int CB = 16;
+    hipLaunchKernelGGL(k_cansee_levels<CB>, dim3(c->npad / CB), dim3(1024), 0, c->stream,
+                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    return SW_OK;
+}
+
+template <int NW>
+int run_round_loop(sw_ctx* c, int r_start, float* tally_ms_out, int* tally_launches_out) {
+    const int np = c->npad, K = c->K;
+    RState init{};
+    init.r = r_start;
+    HIPCHK(c, hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_unres.p, 0, np * sizeof(int32_t), c->stream));
+    const int tally_blocks = np * K / 4;
+    const int mask_blocks = std::min(std::max(c->MCAP / 4, 1), 2048);
+    const uint32_t tot2 = 2u * c->tot;
+    std::vector<Span> tally_spans;
+    RState st{};
+    int launched = 0;
+    for (;;) {
+        CHK(ensure_rounds(c, c->R + launched + c->BATCH + 4));
+        for (int it = 0; it < c->BATCH; ++it) {
+            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(np), 0, c->stream, c->d_state, np, K, (int)c->N,
+                               c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
+                               c->d_lo.p, c->d_lopos.p, c->d_evalround.p, c->d_evalpos.p, c->d_lo_r.p,
+                               c->d_cur.p, c->d_unres.p, c->d_lo_next.p, c->d_pos_next.p, c->d_cand.p,
+                               (const unsigned char*)c->d_res.p);
+            hipLaunchKernelGGL(k_band_masks<NW>, dim3(mask_blocks), dim3(256), 0, c->stream,
+                               (const RState*)c->d_state, (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                               (const int*)c->d_lo_r.p, c->d_Mb.p, np);
+            Span s = span_begin(c);
+            if (c->unit_stake)
+                hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream,
+                                   c->d_state, (const int*)c->d_cand.p, (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                                   (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
+                                   (const uint32_t*)c->d_stake.p, tot2, c->d_res.p, np);
+            else
+                hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream,
+                                   c->d_state, (const int*)c->d_cand.p, (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                                   (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
+                                   (const uint32_t*)c->d_stake.p, tot2, c->d_res.p, np);
+            span_end(c, s);
+            if (c->profiling) tally_spans.push_back(s);
+            c->ctr.kernel_launches += 3;
+        }
+        launched += c->BATCH;
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (st.err) return fail(c, SW_ERANGE, "round table capacity exceeded (internal)");
+        if (st.done) break;
+        if (launched > 64 * 1024 * 1024) return fail(c, SW_EIO, "round loop did not terminate");
+    }
+    c->R = st.max_round + 1;
+    c->ctr.tally_evals += (int64_t)st.evals;
+    c->ctr.round_iterations += st.iter;
+    if (c->profiling) {
+        float ms = 0.f;
+        int cnt = 0;
+        // only the launches that did work (iterations before `done`)
+        for (size_t i = 0; i < tally_spans.size() && (int)i < st.iter - 1; ++i) { ms += span_ms(tally_spans[i]); ++cnt; }
+        *tally_ms_out = ms;
+        *tally_launches_out = cnt;
+    }
+    return SW_OK;
+}
+
+template <int NW>
+int do_divide(sw_ctx* c, int64_t first, int64_t K) {
+    const int np = c->npad;
+    c->ev_used = 0;
+    Span sp_total = span_begin(c);
+    // ---- level buckets + can_see rows ----
+    int hmin = 0x7fffffff, hmax = -1;
+    for (int64_t e = first; e < first + K; ++e) {
+        hmin = std::min(hmin, c->ht[e]);
+        hmax = std::max(hmax, c->ht[e]);
+    }
+    const int nlev = hmax - hmin + 1;
+    CHK(dgrow(c, c->d_lev_cnt, nlev, 0));
+    CHK(dgrow(c, c->d_lev_start, nlev + 1, 0));
+    CHK(dgrow(c, c->d_lev_cursor, nlev, 0));
+    CHK(dgrow(c, c->d_desc, K, 0));
+    if (c->chains_dirty) CHK(rebuild_chains(c));
+    Span sp_cs = span_begin(c);
+    HIPCHK(c, hipMemsetAsync(c->d_lev_cnt.p, 0, nlev * sizeof(int32_t), c->stream));
+    const int eb = (int)((K + 255) / 256);
+    hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, c->stream, (const int*)c->d_ht.p, (int)first, (int)K, hmin, c->d_lev_cnt.p);
+    hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)c->d_lev_cnt.p, nlev, c->d_lev_start.p, c->d_lev_cursor.p);
+    hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, c->stream, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
+                       (const int*)c->d_sp.p, (const int*)c->d_op.p, (int)first, (int)K, hmin,
+                       (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
+    c->ctr.kernel_launches += 3;
+    CHK(launch_cansee<NW>(c, nlev));
+    span_end(c, sp_cs);
+    c->ctr.levels += nlev;
+
+    // ---- round loop ----
+    CHK(ensure_rounds(c, std::max(c->R, 1) + c->BATCH + 4));
+    int r_start = 0x7fffffff;
+    {
+        // members touched by this batch; a member's first event (its root) opens its chain
+        // at round 0: lo[0][m] = root, chain position 0 (swirld.py:195-198)
+        bool row0_dirty = false;
+        for (int64_t e = first; e < first + K; ++e) {
+            const int m = c->cr[e];
+            if (c->front[m] < 0) {
+                c->lo0_h[m] = (int32_t)e;
+                c->front[m] = 0;
+                row0_dirty = true;
+            }
+        }
+        std::vector<char> touched(c->n, 0);
+        for (int64_t e = first; e < first + K; ++e) touched[c->cr[e]] = 1;
+        for (int m = 0; m < c->n; ++m)
+            if (touched[m]) r_start = std::min(r_start, c->front[m]);
+        if (r_start == 0x7fffffff) r_start = 0;
+        if (row0_dirty)
+            HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    Span sp_rl = span_begin(c);
+    float tally_ms = 0.f;
+    int tally_launches = 0;
+    CHK(run_round_loop<NW>(c, r_start, &tally_ms, &tally_launches));
+    span_end(c, sp_rl);
+
+    // ---- finalize ----
+    Span sp_fin = span_begin(c);
+    const int R = c->R;
+    CHK(ensure_rounds(c, R + 2));
+    {
+        const int blocks = (int)std::min<int64_t>((K + 3) / 4, 8192);
+        hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, c->stream, (const int*)c->d_L.p,
+                           (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)first, (int)K, c->d_round.p, c->d_S.p, np);
+        const int total = (R - r_start) * np;
+        if (total > 0)
+            hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                               (const int*)c->d_lo.p, R, r_start, np, c->d_wit.p);
+        c->ctr.kernel_launches += 2;
+    }
+    span_end(c, sp_fin);
+    // host mirror of the per-member front round
+    {
+        std::vector<int32_t> rows((size_t)(R - r_start) * np);
+        if (!rows.empty())
+            HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_lo.p + (size_t)r_start * np, rows.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        span_end(c, sp_total);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int m = 0; m < c->n; ++m)
+            for (int r = R - 1; r >= r_start; --r)
+                if (rows[(size_t)(r - r_start) * np + m] != SW_INF) { c->front[m] = std::max(c->front[m], r); break; }
+    }
+    HIPCHK(c, hipGetLastError());
+    c->sw_dirty_from = std::min(c->sw_dirty_from, std::max(r_start, 1));
+    c->divided = first + K;
+    c->ctr.events_divided += K;
+    c->ctr.rounds = R;
+    if (c->profiling) {
+        c->tm.can_see_ms = span_ms(sp_cs);
+        c->tm.rounds_ms = span_ms(sp_rl);
+        c->tm.tally_ms = tally_ms;
+        c->tm.tally_launches = tally_launches;
+        c->tm.finalize_ms = span_ms(sp_fin);
+        c->tm.total_ms = span_ms(sp_total);
+    }
+    return SW_OK;
+}
+
+template <int NW>
+int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
+    const int np = c->npad, R = c->R;
+    c->ev_used = 0;
+    Span sp = span_begin(c);
+    int max_c = 0;
+    while (max_c < R && c->cons_h[max_c]) ++max_c;
+    // voter masks for rounds whose witness set may have changed
+    if (R > c->Sw_rows) {
+        int nr = c->Sw_rows ? c->Sw_rows : 256;
+        while (nr < R) nr *= 2;
+        CHK(dgrow(c, c->d_Sw, (size_t)nr * np * NW, (size_t)c->Sw_rows * np * NW));
+        c->Sw_rows = nr;
+    }
+    const uint32_t tot2 = 2u * c->tot;
+    const int r0 = std::max(1, std::min(c->sw_dirty_from, R));
+    HIPCHK(c, hipMemsetAsync(c->d_fc, 0, sizeof(FameCounters), c->stream));
+    if (R > r0) {
+        const int total = (R - r0) * np;
+        if (c->unit_stake)
+            hipLaunchKernelGGL((k_voter_masks<NW, true>), dim3((total + 3) / 4), dim3(256), 0, c->stream,
+                               (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const u64*)c->d_S.p,
+                               (const uint32_t*)c->d_stake.p, tot2, r0, R, np, c->d_Sw.p, c->d_fc);
+        else
+            hipLaunchKernelGGL((k_voter_masks<NW, false>), dim3((total + 3) / 4), dim3(256), 0, c->stream,
+                               (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const u64*)c->d_S.p,
+                               (const uint32_t*)c->d_stake.p, tot2, r0, R, np, c->d_Sw.p, c->d_fc);
+        c->ctr.kernel_launches++;
+    }
+    c->sw_dirty_from = std::max(R, 1);
+    HIPCHK(c, hipMemsetAsync(c->d_newc.p, 0, R, c->stream));
+    if (R > max_c) {
+        if (c->unit_stake)
+            hipLaunchKernelGGL((k_elections<NW, true>), dim3(R - max_c), dim3(np), 0, c->stream, (const int*)c->d_wit.p,
+                               (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
+                               tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
+        else
+            hipLaunchKernelGGL((k_elections<NW, false>), dim3(R - max_c), dim3(np), 0, c->stream, (const int*)c->d_wit.p,
+                               (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
+                               tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
+        c->ctr.kernel_launches++;
+    }
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned char> newc(R);
+    FameCounters fc{};
+    HIPCHK(c, hipMemcpyAsync(newc.data(), c->d_newc.p, R, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&fc, c->d_fc, sizeof fc, hipMemcpyDeviceToHost, c->stream));
+    span_end(c, sp);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int cnt = 0;
+    for (int r = 0; r < R; ++r)
+        if (newc[r]) {
+            c->cons_h[r] = 1;
+            if (cnt < cap && new_rounds) new_rounds[cnt] = r;
+            ++cnt;
+        }
+    if (n_new) *n_new = cnt;
+    c->ctr.voter_evals += (int64_t)fc.voter_evals;
+    c->ctr.majority_evals += (int64_t)fc.majority_evals;
+    if (c->profiling) c->tm.fame_ms = span_ms(sp);
+    if (cnt > cap) return fail(c, SW_ERANGE, "new_rounds capacity %d < %d", cap, cnt);
+    return SW_OK;
+}
+
+template <class T>
+int get_round_rows(sw_ctx* c, const T* src, int r0, int r1, T* out, T absent) {
+    if (!c || !out) return SW_EINVAL;
+    if (r0 < 0 || r1 < r0) return fail(c, SW_ERANGE, "bad round range");
+    const int np = c->npad, n = c->n;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rr = std::min(r1, c->R);
+    std::vector<T> tmp((size_t)std::max(rr - r0, 0) * np);
+    if (!tmp.empty()) {
+        HIPCHK(c, hipMemcpyAsync(tmp.data(), src + (size_t)r0 * np, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    for (int r = r0; r < r1; ++r)
+        for (int m = 0; m < n; ++m)
+            out[(size_t)(r - r0) * n + m] = r < rr ? tmp[(size_t)(r - r0) * np + m] : absent;
+    return SW_OK;
+}
+
+}  // namespace
+
+// ====================================================================================
+//                                     C-ABI
+// ====================================================================================
+extern "C" {
+
+int sw_version(void) { return 1; }
+
+const char* sw_last_error(const sw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sw_create(int n_members, const uint64_t* stake, int coin_period, int device, sw_ctx** out) {
+    if (!out) return fail(nullptr, SW_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_members < 1 || n_members > SW_MAX_MEMBERS) return fail(nullptr, SW_EINVAL, "n_members must be in [1, %d]", SW_MAX_MEMBERS);
+    if (!stake) return fail(nullptr, SW_EINVAL, "stake is NULL");
+    if (coin_period < 1) return fail(nullptr, SW_EINVAL, "coin_period must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SW_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, SW_ENODEV, "device %d out of range (%d devices)", device, ndev);
+    uint64_t tot = 0;
+    bool unit = true;
+    for (int i = 0; i < n_members; ++i) {
+        if (stake[i] > (1ull << 30)) return fail(nullptr, SW_EOVERFLOW, "stake[%d] too large for the 32-bit tally", i);
+        tot += stake[i];
+        unit = unit && stake[i] == 1;
+    }
+    if (tot >= (1ull << 30)) return fail(nullptr, SW_EOVERFLOW, "total stake %llu >= 2^30", (unsigned long long)tot);
+    sw_ctx* c = new sw_ctx();
+    c->n = n_members;
+    int nw = 1;
+    while (nw * 64 < n_members) nw *= 2;
+    c->nw = nw;
+    c->npad = nw * 64;
+    c->coin_period = coin_period;
+    c->device = device;
+    c->unit_stake = unit;
+    c->tot = (uint32_t)tot;
+    c->stake_h.assign(c->npad, 0);
+    for (int i = 0; i < n_members; ++i) c->stake_h[i] = (uint32_t)stake[i];
+    c->head.assign(n_members, -1);
+    c->front.assign(n_members, -1);
+    c->lo0_h.assign(c->npad, SW_INF);
+    c->MCAP = std::max(32 * c->npad, 2048);
+    if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, atoi(s));
+    if (const char* s = getenv("SW_BAND")) c->MCAP = std::max(64, atoi(s));
+    if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
+    c->K = (c->K + 3) & ~3;  // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway)
+    auto bail = [&](int rc) { g_create_error = c->err; sw_destroy(c); return rc; };
+#define CCHK(expr) do { int rc_ = (expr); if (rc_ != SW_OK) return bail(rc_); } while (0)
+#define CHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, SW_EIO, "%s: %s", #expr, hipGetErrorString(e_)); return bail(SW_EIO); } } while (0)
+    CHIP(hipSetDevice(device));
+    CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CHIP(hipMalloc((void**)&c->d_state, sizeof(RState)));
+    CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
+    const int np = c->npad;
+    CCHK(dgrow(c, c->d_stake, np, 0));
+    CHIP(hipMemcpy(c->d_stake.p, c->stake_h.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CCHK(dgrow(c, c->d_evalround, np, 0));
+    CCHK(dgrow(c, c->d_evalpos, np, 0));
+    CCHK(dgrow(c, c->d_lo_r, np, 0));
+    CCHK(dgrow(c, c->d_cur, np, 0));
+    CCHK(dgrow(c, c->d_unres, np, 0));
+    CCHK(dgrow(c, c->d_lo_next, np, 0));
+    CCHK(dgrow(c, c->d_pos_next, np, 0));
+    CCHK(dgrow(c, c->d_cand, (size_t)np * c->K, 0));
+    CCHK(dgrow(c, c->d_res, (size_t)np * c->K, 0));
+    CCHK(dgrow(c, c->d_Mb, (size_t)c->MCAP * c->nw, 0));
+    CCHK(fill_i32(c, c->d_evalround.p, np, -1));
+    CCHK(fill_i32(c, c->d_evalpos.p, np, 0));
+    CCHK(fill_i32(c, c->d_lo_r.p, np, SW_INF));
+    CCHK(fill_i32(c, c->d_cur.p, np, 0));
+    CCHK(fill_i32(c, c->d_lo_next.p, np, SW_INF));
+    CCHK(fill_i32(c, c->d_pos_next.p, np, 0));
+    CHIP(hipMemsetAsync(c->d_res.p, 0, (size_t)np * c->K, c->stream));
+    CCHK(ensure_rounds(c, 256));
+    CHIP(hipStreamSynchronize(c->stream));
+#undef CCHK
+#undef CHIP
+    *out = c;
+    return SW_OK;
+}
+
+int sw_destroy(sw_ctx* c) {
+    if (!c) return SW_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_round); dfree(c->d_L);
+    dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
+    dfree(c->d_chain_start); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
+    dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
+    dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
+    dfree(c->d_pos_next); dfree(c->d_cand); dfree(c->d_res); dfree(c->d_Mb);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_fc) (void)hipFree(c->d_fc);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SW_OK;
+}
+
+int sw_reserve(sw_ctx* c, int64_t n_events) {
+    if (!c || n_events < 0) return SW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    return ensure_events(c, n_events);
+}
+
+int64_t sw_num_events(const sw_ctx* c) { return c ? c->N : 0; }
+
+int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t* self_parent,
+                     const int32_t* other_parent, const double* t, const uint8_t* sig64) {
+    if (!c) return SW_EINVAL;
+    if (K < 0 || (K > 0 && (!creator || !self_parent || !other_parent))) return fail(c, SW_EINVAL, "NULL event arrays");
+    if (K == 0) return SW_OK;
+    if (c->N + K > 0x7ffffff0ll) return fail(c, SW_ERANGE, "more than 2^31 events");
+    // structural validation (swirld.py:104-108) before anything is stored
+    for (int64_t i = 0; i < K; ++i) {
+        const int64_t e = c->N + i;
+        const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
+        if (m < 0 || m >= c->n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
+        if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
+        if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
+        if (s >= 0) {
+            const int32_t cs = s < c->N ? c->cr[s] : creator[s - c->N];
+            const int32_t co = o < c->N ? c->cr[o] : creator[o - c->N];
+            if (cs != m) return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
+            if (co == m) return fail(c, SW_EINVAL, "event %lld: other-parent is by the same member", (long long)e);
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_events(c, c->N + K));
+    const int64_t N0 = c->N;
+    c->cr.resize(N0 + K); c->sp.resize(N0 + K); c->op.resize(N0 + K); c->ht.resize(N0 + K);
+    std::vector<unsigned char> coin(K);
+    for (int64_t i = 0; i < K; ++i) {
+        const int64_t e = N0 + i;
+        const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
+        c->cr[e] = m; c->sp[e] = s; c->op[e] = o;
+        c->ht[e] = s < 0 ? 0 : std::max(c->ht[s], c->ht[o]) + 1;  // swirld.py:117-120
+        if (c->head[m] != s) c->has_forks = true;  // second child of s, or a second root
+        c->head[m] = (int32_t)e;
+        coin[i] = sig64 ? (unsigned char)(sig64[64 * i] >> 7) : 0;  // swirld.py:272
+    }
+    c->N = N0 + K;
+    c->chains_dirty = true;
+    const size_t b4 = (size_t)K * sizeof(int32_t);
+    HIPCHK(c, hipMemcpyAsync(c->d_cr.p + N0, c->cr.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_sp.p + N0, c->sp.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_op.p + N0, c->op.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ht.p + N0, c->ht.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_coin.p + N0, coin.data(), K, hipMemcpyHostToDevice, c->stream));
+    if (t) HIPCHK(c, hipMemcpyAsync(c->d_t.p + N0, t, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemsetAsync(c->d_t.p + N0, 0, (size_t)K * sizeof(double), c->stream));
+    if (sig64) HIPCHK(c, hipMemcpyAsync(c->d_sig.p + (size_t)N0 * 64, sig64, (size_t)K * 64, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemsetAsync(c->d_sig.p + (size_t)N0 * 64, 0, (size_t)K * 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_round.p + N0, 0xff, b4, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller buffers may be released on return
+    return SW_OK;
+}
+
+int sw_divide_rounds(sw_ctx* c, int64_t first, int64_t K) {
+    if (!c) return SW_EINVAL;
+    if (K < 0 || first < 0 || first + K > c->N) return fail(c, SW_ERANGE, "events [%lld, %lld) outside the stored hashgraph", (long long)first, (long long)(first + K));
+    if (first != c->divided) return fail(c, SW_EINVAL, "divide_rounds must continue at event %lld (got %lld): every event is divided once, in order", (long long)c->divided, (long long)first);
+    if (K == 0) return SW_OK;
+    if (c->has_forks) return fail(c, SW_ENOTSUP, "the hashgraph contains a fork; the round-synchronous path requires one self-parent chain per member");
+    HIPCHK(c, hipSetDevice(c->device));
+    switch (c->nw) {
+        case 1: return do_divide<1>(c, first, K);
+        case 2: return do_divide<2>(c, first, K);
+        case 4: return do_divide<4>(c, first, K);
+        case 8: return do_divide<8>(c, first, K);
+        case 16: return do_divide<16>(c, first, K);
+    }
+    return fail(c, SW_EINVAL, "unsupported member count");
+}
+
+int sw_decide_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
+    if (!c) return SW_EINVAL;
+    if (n_new) *n_new = 0;
+    if (c->R <= 0) return fail(c, SW_EINVAL, "decide_fame before any witness exists (max() of an empty dict in the reference, swirld.py:225)");
+    HIPCHK(c, hipSetDevice(c->device));
+    switch (c->nw) {
+        case 1: return do_fame<1>(c, new_rounds, cap, n_new);
+        case 2: return do_fame<2>(c, new_rounds, cap, n_new);
+        case 4: return do_fame<4>(c, new_rounds, cap, n_new);
+        case 8: return do_fame<8>(c, new_rounds, cap, n_new);
+        case 16: return do_fame<16>(c, new_rounds, cap, n_new);
+    }
+    return fail(c, SW_EINVAL, "unsupported member count");
+}
+
+int sw_rewind(sw_ctx* c) {
+    if (!c) return SW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t rows = (size_t)c->Rcap * c->npad;
+    CHK(fill_i32(c, c->d_lo.p, rows, SW_INF));
+    CHK(fill_i32(c, c->d_lopos.p, rows, 0));
+    CHK(fill_i32(c, c->d_wit.p, rows, -1));
+    HIPCHK(c, hipMemsetAsync(c->d_fam.p, 0xff, rows, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cons.p, 0, c->Rcap, c->stream));
+    CHK(fill_i32(c, c->d_evalround.p, c->npad, -1));
+    CHK(fill_i32(c, c->d_evalpos.p, c->npad, 0));
+    if (c->N) HIPCHK(c, hipMemsetAsync(c->d_round.p, 0xff, (size_t)c->N * sizeof(int32_t), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::fill(c->front.begin(), c->front.end(), -1);
+    std::fill(c->lo0_h.begin(), c->lo0_h.end(), SW_INF);
+    std::fill(c->cons_h.begin(), c->cons_h.end(), 0);
+    c->divided = 0;
+    c->R = 0;
+    c->sw_dirty_from = 1;
+    c->transactions.clear();
+    return SW_OK;
+}
+
+int sw_find_order(sw_ctx* c, const int32_t*, int, int32_t*, int64_t, int64_t* n_out) {
+    if (n_out) *n_out = 0;
+    return fail(c, SW_ENOTSUP, "find_order is not implemented yet");
+}
+
+// ---- getters ----
+static int get_i32(sw_ctx* c, const int32_t* src, int64_t first, int64_t K, int32_t* out, int64_t limit) {
+    if (!c || !out) return SW_EINVAL;
+    if (first < 0 || K < 0 || first + K > limit) return fail(c, SW_ERANGE, "range [%lld, %lld) outside [0, %lld)", (long long)first, (long long)(first + K), (long long)limit);
+    if (!K) return SW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, src + first, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SW_OK;
+}
+
+int sw_get_height(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (first < 0 || K < 0 || first + K > c->N) return fail(c, SW_ERANGE, "range outside the stored hashgraph");
+    std::copy(c->ht.begin() + first, c->ht.begin() + first + K, out);
+    return SW_OK;
+}
+
+int sw_get_round(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
+    return get_i32(c, c ? c->d_round.p : nullptr, first, K, out, c ? c->divided : 0);
+}
+
+int sw_get_can_see(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (first < 0 || K < 0 || first + K > c->divided) return fail(c, SW_ERANGE, "range outside the divided events");
+    if (!K) return SW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int np = c->npad, n = c->n;
+    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (np * 4));
+    std::vector<int32_t> tmp((size_t)std::min(chunk, K) * np);
+    for (int64_t a = 0; a < K; a += chunk) {
+        const int64_t m = std::min(chunk, K - a);
+        HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_L.p + (size_t)(first + a) * np, (size_t)m * np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t i = 0; i < m; ++i) memcpy(out + (size_t)(a + i) * n, tmp.data() + (size_t)i * np, n * sizeof(int32_t));
+    }
+    return SW_OK;
+}
+
+int sw_max_round(sw_ctx* c, int* out) {
+    if (!c || !out) return SW_EINVAL;
+    *out = c->R - 1;
+    return SW_OK;
+}
+
+int sw_get_witnesses(sw_ctx* c, int r0, int r1, int32_t* out) {
+    return get_round_rows<int32_t>(c, c ? c->d_wit.p : nullptr, r0, r1, out, -1);
+}
+
+int sw_get_famous(sw_ctx* c, int r0, int r1, int8_t* out) {
+    return get_round_rows<signed char>(c, c ? c->d_fam.p : nullptr, r0, r1, (signed char*)out, (signed char)-1);
+}
+
+int sw_get_consensus(sw_ctx* c, int r0, int r1, uint8_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (r0 < 0 || r1 < r0) return fail(c, SW_ERANGE, "bad round range");
+    for (int r = r0; r < r1; ++r) out[r - r0] = (r < c->R && r < (int)c->cons_h.size()) ? c->cons_h[r] : 0;
+    return SW_OK;
+}
+
+int sw_get_sees_mask(sw_ctx* c, int64_t first, int64_t K, uint64_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (first < 0 || K < 0 || first + K > c->divided) return fail(c, SW_ERANGE, "range outside the divided events");
+    if (!K) return SW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nw = c->nw, nwo = (c->n + 63) / 64;
+    std::vector<u64> tmp((size_t)K * nw);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_S.p + (size_t)first * nw, tmp.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < K; ++i)
+        for (int j = 0; j < nwo; ++j) out[(size_t)i * nwo + j] = tmp[(size_t)i * nw + j];
+    return SW_OK;
+}
+
+int sw_get_vote(sw_ctx* c, int, int, int, int, int8_t*) { return fail(c, SW_ENOTSUP, "sw_get_vote is not implemented yet"); }
+
+int sw_num_ordered(sw_ctx* c, int64_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    *out = (int64_t)c->transactions.size();
+    return SW_OK;
+}
+
+int sw_get_transactions(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (first < 0 || K < 0 || first + K > (int64_t)c->transactions.size()) return fail(c, SW_ERANGE, "range outside the ordered events");
+    for (int64_t i = 0; i < K; ++i) out[i] = (int32_t)c->transactions[first + i];
+    return SW_OK;
+}
+
+int sw_get_counters(sw_ctx* c, sw_counters* out) {
+    if (!c || !out) return SW_EINVAL;
+    *out = c->ctr;
+    return SW_OK;
+}
+
+int sw_set_profiling(sw_ctx* c, int enable) {
+    if (!c) return SW_EINVAL;
+    c->profiling = enable != 0;
+    return SW_OK;
+}
+
+int sw_get_timings(sw_ctx* c, sw_timings* out) {
+    if (!c || !out) return SW_EINVAL;
+    *out = c->tm;
+    return SW_OK;
+}
+
+int sw_synchronize(sw_ctx* c) {
+    if (!c) return SW_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Array-in / array-out front end of the C-ABI: one `Hashgraph` = the voting state of
+one Node view, resident in HBM.  Mirrors the reference's hot-path methods
+(swirld.py:187-311) on dense event / member indices."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Counters, SwirldHipError, Timings
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Hashgraph:
+    def __init__(self, n_members, stake=None, coin_period=6, device=0):
+        self._L = _lib.load()
+        self.n = int(n_members)
+        st = np.ones(self.n, np.uint64) if stake is None else np.ascontiguousarray(stake, np.uint64)
+        if st.shape != (self.n,):
+            raise ValueError("stake must have one entry per member")
+        self.stake = st
+        self._h = C.c_void_p()
+        rc = self._L.sw_create(self.n, _p(st), int(coin_period), int(device), C.byref(self._h))
+        if rc != 0:
+            raise SwirldHipError(rc, (self._L.sw_last_error(None) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.sw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SwirldHipError(rc, (self._L.sw_last_error(self._h) or b"").decode())
+
+    # ---- ingest (Node.add_event, swirld.py:114-120) ----
+    def reserve(self, n_events):
+        self._chk(self._L.sw_reserve(self._h, int(n_events)))
+
+    def append_events(self, creator, self_parent, other_parent, t=None, sig=None):
+        creator = np.ascontiguousarray(creator, np.int32)
+        sp = np.ascontiguousarray(self_parent, np.int32)
+        op = np.ascontiguousarray(other_parent, np.int32)
+        K = creator.shape[0]
+        if sp.shape != (K,) or op.shape != (K,):
+            raise ValueError("creator / parents must have equal length")
+        t = None if t is None else np.ascontiguousarray(t, np.float64)
+        sig = None if sig is None else np.ascontiguousarray(sig, np.uint8).reshape(K, 64)
+        self._chk(self._L.sw_append_events(self._h, K, _p(creator), _p(sp), _p(op), _p(t), _p(sig)))
+
+    @property
+    def num_events(self):
+        return int(self._L.sw_num_events(self._h))
+
+    # ---- hot path ----
+    def divide_rounds(self, first, K):
+        self._chk(self._L.sw_divide_rounds(self._h, int(first), int(K)))
+
+    def decide_fame(self):
+        cap = self.max_round + 2
+        out = np.empty(max(cap, 1), np.int32)
+        n_new = C.c_int()
+        self._chk(self._L.sw_decide_fame(self._h, _p(out), int(out.shape[0]), C.byref(n_new)))
+        return out[: n_new.value].copy()
+
+    def find_order(self, rounds):
+        rounds = np.ascontiguousarray(sorted(int(r) for r in rounds), np.int32)
+        cap = self.num_events
+        out = np.empty(max(cap, 1), np.int32)
+        n_out = C.c_int64()
+        self._chk(self._L.sw_find_order(self._h, _p(rounds), len(rounds), _p(out), cap, C.byref(n_out)))
+        return out[: n_out.value].copy()
+
+    # ---- state views ----
+    @property
+    def max_round(self):
+        v = C.c_int()
+        self._chk(self._L.sw_max_round(self._h, C.byref(v)))
+        return v.value
+
+    def rounds(self, first=0, K=None):
+        K = self.num_events - first if K is None else K
+        out = np.empty(K, np.int32)
+        self._chk(self._L.sw_get_round(self._h, first, K, _p(out)))
+        return out
+
+    def heights(self, first=0, K=None):
+        K = self.num_events - first if K is None else K
+        out = np.empty(K, np.int32)
+        self._chk(self._L.sw_get_height(self._h, first, K, _p(out)))
+        return out
+
+    def can_see(self, first=0, K=None):
+        K = self.num_events - first if K is None else K
+        out = np.empty((K, self.n), np.int32)
+        self._chk(self._L.sw_get_can_see(self._h, first, K, _p(out)))
+        return out
+
+    def sees_masks(self, first=0, K=None):
+        K = self.num_events - first if K is None else K
+        out = np.empty((K, (self.n + 63) // 64), np.uint64)
+        self._chk(self._L.sw_get_sees_mask(self._h, first, K, _p(out)))
+        return out
+
+    def witnesses(self, r0=0, r1=None):
+        r1 = self.max_round + 1 if r1 is None else r1
+        out = np.empty((max(r1 - r0, 0), self.n), np.int32)
+        self._chk(self._L.sw_get_witnesses(self._h, r0, r1, _p(out)))
+        return out
+
+    def famous(self, r0=0, r1=None):
+        r1 = self.max_round + 1 if r1 is None else r1
+        out = np.empty((max(r1 - r0, 0), self.n), np.int8)
+        self._chk(self._L.sw_get_famous(self._h, r0, r1, _p(out)))
+        return out
+
+    def consensus(self, r0=0, r1=None):
+        r1 = self.max_round + 1 if r1 is None else r1
+        out = np.empty(max(r1 - r0, 0), np.uint8)
+        self._chk(self._L.sw_get_consensus(self._h, r0, r1, _p(out)))
+        return out
+
+    def transactions(self):
+        n = C.c_int64()
+        self._chk(self._L.sw_num_ordered(self._h, C.byref(n)))
+        out = np.empty(n.value, np.int32)
+        self._chk(self._L.sw_get_transactions(self._h, 0, n.value, _p(out)))
+        return out
+
+    # ---- measurement ----
+    def counters(self):
+        c = Counters()
+        self._chk(self._L.sw_get_counters(self._h, C.byref(c)))
+        return {k: int(getattr(c, k)) for k, _ in Counters._fields_}
+
+    def set_profiling(self, enable=True):
+        self._chk(self._L.sw_set_profiling(self._h, 1 if enable else 0))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self._L.sw_get_timings(self._h, C.byref(t)))
+        return {k: (int(getattr(t, k)) if k == "tally_launches" else float(getattr(t, k)))
+                for k, _ in Timings._fields_}
+
+    def rewind(self):
+        """Forget all voting state; the ingested events stay resident (bench utility)."""
+        self._chk(self._L.sw_rewind(self._h))
+
+    def synchronize(self):
+        self._chk(self._L.sw_synchronize(self._h))
+
+
+def synth_hashgraph(n, N, seed, mode=0, p0=0.0, p1=0.0, with_sig=True):
+    """Host-side synthetic gossip hashgraph (csrc/synth.cpp): returns
+    (creator, self_parent, other_parent, t, sig) as numpy arrays."""
+    L = _lib.load()
+    cr = np.empty(N, np.int32)
+    sp = np.empty(N, np.int32)
+    op = np.empty(N, np.int32)
+    t = np.empty(N, np.float64)
+    sig = np.empty((N, 64), np.uint8) if with_sig else None
+    rc = L.sw_synth_hashgraph(int(n), int(N), int(seed), int(mode), float(p0), float(p1),
+                              _p(cr), _p(sp), _p(op), _p(t), _p(sig))
+    if rc != 0:
+        raise SwirldHipError(rc, "sw_synth_hashgraph: invalid arguments")
+    return cr, sp, op, t, sig

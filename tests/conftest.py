@@ -1,0 +1,40 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    g["n"] = int(g["n"])
+    g["chunk"] = int(g["chunk"])
+    off = g["wit_order_off"]
+    g["wit_order"] = [g["wit_order_flat"][off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    return g
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import importlib
+    build = importlib.import_module("py-swirld_amd.build")
+    build.build()
+    return importlib.import_module("py-swirld_amd")

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference/swirld.py, imported through tests/refharness.py with the pysodium
+stand-in) on seeded synthetic event streams.  Runs in the authoring container only
+(the reference tree does not travel to the GPU box); the resulting small fixtures are
+committed and pin both the CPU oracle (tests/test_oracle_golden.py) and the HIP path
+(tests/test_gpu_parity.py).
+
+Each fixture stores the input stream (so it does not depend on the generator staying
+bit-stable), the call schedule, and every piece of Node state the hot path produces:
+round, height, can_see, witnesses (+ dict order), famous, consensus, votes,
+transactions, tbd, and the per-call return values of decide_fame / find_order.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+from refharness import RefRun  # noqa: E402
+from synth_util import synth  # noqa: E402
+
+# name, n, N, seed, mode, p0, p1, stake, chunk (None = one batch call)
+CASES = [
+    ("n4_s1_batch", 4, 400, 1, 0, 0, 0, None, None),
+    ("n4_s2_batch", 4, 400, 2, 0, 0, 0, None, None),
+    ("n4_s3_batch", 4, 600, 3, 0, 0, 0, None, None),
+    ("n4_s5_chunk1", 4, 400, 5, 0, 0, 0, None, 1),
+    ("n4_s6_chunk7", 4, 400, 6, 0, 0, 0, None, 7),
+    ("n5_s1_batch", 5, 500, 1, 0, 0, 0, None, None),
+    ("n7_s2_chunk13", 7, 700, 2, 0, 0, 0, None, 13),
+    ("n16_s3_batch", 16, 2000, 3, 0, 0, 0, None, None),
+    ("n16_s4_chunk50", 16, 2000, 4, 0, 0, 0, None, 50),
+    ("n16_s4_chunk250", 16, 2000, 4, 0, 0, 0, None, 250),
+    ("n33_s5_batch", 33, 3000, 5, 0, 0, 0, None, None),
+    ("n16_s7_cliques", 16, 2000, 7, 1, 0.05, 0, None, None),
+    ("n16_s8_slow", 16, 2000, 8, 2, 0.25, 0.05, None, None),
+    ("n16_s9_stale", 16, 2000, 9, 3, 0.5, 0, None, None),
+    ("n10_s1_stake", 10, 1500, 1, 0, 0, 0, [1] * 9 + [2], None),
+    ("n12_s2_stake", 12, 1500, 2, 0, 0, 0, [1, 1, 1, 2, 1, 1, 1, 1, 2, 1, 1, 1], None),
+    ("n6_s3_stuck_stake", 6, 600, 3, 0, 0, 0, [3, 1, 4, 1, 5, 2], None),
+    ("n64_s1_batch", 64, 6000, 1, 0, 0, 0, None, None),
+    ("n64_s2_slow_chunk1000", 64, 5000, 2, 2, 0.2, 0.1, None, 1000),
+    ("n70_s3_batch", 70, 4000, 3, 0, 0, 0, None, None),
+    ("n130_s4_batch", 130, 14000, 4, 0, 0, 0, None, None),
+]
+
+
+def run_case(n, stream, stake, chunk):
+    cr, sp, op, t, sig = stream
+    N = len(cr)
+    ref = RefRun(n, stake)
+    chunk = chunk or N
+    new_c_flat, new_c_off, tx_off = [], [0], [0]
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        ref.append(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+        ref.divide_rounds(a, b - a)
+        nc = ref.decide_fame()
+        ref.find_order(nc)
+        new_c_flat += list(nc)
+        new_c_off.append(len(new_c_flat))
+        tx_off.append(len(ref.node.transactions))
+    ex = ref.extract()
+    wo_flat = np.concatenate(ex["wit_order"]) if ex["wit_order"] else np.zeros(0, np.int32)
+    wo_off = np.cumsum([0] + [len(o) for o in ex["wit_order"]]).astype(np.int32)
+    return dict(
+        n=np.int32(n), stake=np.array([1] * n if stake is None else stake, np.uint64),
+        chunk=np.int64(chunk), creator=cr, self_parent=sp, other_parent=op, t=t, sig=sig,
+        round=ex["round"], height=ex["height"], can_see=ex["can_see"],
+        witnesses=ex["witnesses"], wit_order_flat=wo_flat.astype(np.int32), wit_order_off=wo_off,
+        famous=ex["famous"], consensus=ex["consensus"], votes=ex["votes"],
+        transactions=ex["transactions"], tbd=ex["tbd"],
+        new_c_flat=np.array(new_c_flat, np.int32), new_c_off=np.array(new_c_off, np.int32),
+        tx_off=np.array(tx_off, np.int64))
+
+
+def add_forks(stream, n, seed, n_forks):
+    """Append forked events: same creator and self-parent as an existing event, other
+    other-parent.  The reference accepts these (no fork detection, README.md:84)."""
+    cr, sp, op, t, sig = [a.copy() for a in stream]
+    rng = np.random.default_rng(seed)
+    cr, sp, op, t = list(cr), list(sp), list(op), list(t)
+    sig = list(sig)
+    N0 = len(cr)
+    for _ in range(n_forks):
+        i = int(rng.integers(n, N0))
+        cands = [k for k in range(N0) if cr[k] != cr[i] and k != op[i]]
+        o = int(rng.choice(cands))
+        cr.append(cr[i]); sp.append(sp[i]); op.append(o); t.append(float(len(t)))
+        sig.append(rng.integers(0, 256, 64, dtype=np.uint8))
+        # a descendant of the fork, created by a third member, so that the fork is seen
+        third = int(rng.choice([c for c in range(n) if c != cr[i]]))
+        heads = [k for k in range(len(cr) - 1) if cr[k] == third]
+        cr.append(third); sp.append(max(heads)); op.append(len(cr) - 2); t.append(float(len(t)))
+        sig.append(rng.integers(0, 256, 64, dtype=np.uint8))
+    return (np.array(cr, np.int32), np.array(sp, np.int32), np.array(op, np.int32),
+            np.array(t, np.float64), np.array(sig, np.uint8).reshape(-1, 64))
+
+
+def main():
+    for name, n, N, seed, mode, p0, p1, stake, chunk in CASES:
+        stream = synth(n, N, seed, mode, p0, p1)
+        out = run_case(n, stream, stake, chunk)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-28s R=%3d consensus=%3d tx=%5d votes=%6d  %6.1f KB" % (
+            name, out["witnesses"].shape[0], int(out["consensus"].sum()),
+            len(out["transactions"]), len(out["votes"]), os.path.getsize(path) / 1024))
+    # forked DAG (oracle-only parity: the bulk HIP path refuses forks)
+    base = synth(8, 500, 11, 0, 0, 0)
+    stream = add_forks(base, 8, 11, 6)
+    out = run_case(8, stream, None, None)
+    path = os.path.join(HERE, "n8_s11_forks.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s R=%3d consensus=%3d tx=%5d" % ("n8_s11_forks", out["witnesses"].shape[0],
+                                               int(out["consensus"].sum()), len(out["transactions"])))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads, and exports every symbol that
+include/swirld_hip.h declares; host-only entry points work; creating a context without a
+GPU fails loudly (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "swirld_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sw_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(pkg):
+    import ctypes
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "%s declared in swirld_hip.h but not exported" % s
+    import importlib
+    L = importlib.import_module("py-swirld_amd._lib")
+    assert sorted(L.SIGNATURES) == syms, "ctypes table out of sync with the header"
+    assert lib.sw_version() == 1
+
+
+def test_synth_is_a_valid_forkfree_dag(pkg):
+    for mode, p0, p1 in [(0, 0, 0), (1, 0.05, 0), (2, 0.25, 0.05), (3, 0.5, 0)]:
+        n, N = 12, 3000
+        cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 7, mode, p0, p1)
+        assert (cr[:n] == np.arange(n)).all() and (sp[:n] == -1).all() and (op[:n] == -1).all()
+        idx = np.arange(n, N)
+        assert (sp[n:] < idx).all() and (op[n:] < idx).all() and (sp[n:] >= 0).all()
+        assert (cr[sp[n:]] == cr[n:]).all() and (cr[op[n:]] != cr[n:]).all()
+        head = {}
+        for e in range(N):  # each member's events form one self-parent chain
+            assert head.get(cr[e], -1) == sp[e]
+            head[cr[e]] = e
+        cr2 = pkg.synth_hashgraph(n, N, 7, mode, p0, p1)[0]
+        assert (cr == cr2).all()
+        assert sig.shape == (N, 64) and (t == np.arange(N)).all()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_no_cpu_fallback(pkg):
+    with pytest.raises(pkg.SwirldHipError) as ei:
+        pkg.Hashgraph(4)
+    assert ei.value.code == -19  # SW_ENODEV

@@ -1,0 +1,199 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against
+ (1) every fork-free golden fixture of the unmodified reference (bit-exact), with the
+     recorded call schedule (batch and incremental);
+ (2) the CPU oracle on fresh seeded streams at sizes it finishes in seconds, including
+     n = 64 / 100k (BASELINE.json configs[1]) and a 256-member prefix;
+ (3) size-independent properties at the full 256-member / 1M-event size.
+Bit-exact: round, can_see, witness table, famous, consensus, new_c, sees-masks."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FORKFREE = [n for n in golden_names() if "forks" not in n]
+
+
+def run_schedule(h, g):
+    N, chunk = len(g["creator"]), g["chunk"]
+    calls = 0
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        h.append_events(g["creator"][a:b], g["self_parent"][a:b], g["other_parent"][a:b],
+                        g["t"][a:b], g["sig"][a:b])
+        h.divide_rounds(a, b - a)
+        nc = h.decide_fame()
+        exp_nc = g["new_c_flat"][g["new_c_off"][calls]:g["new_c_off"][calls + 1]]
+        assert list(nc) == list(exp_nc), "new_c of call %d" % calls
+        calls += 1
+
+
+def assert_state_equal(h, exp_round, exp_cs, exp_wit, exp_fam_by_event, exp_cons):
+    assert np.array_equal(h.rounds(), exp_round)
+    assert np.array_equal(h.can_see(), exp_cs)
+    wit = h.witnesses()
+    assert np.array_equal(wit, exp_wit)
+    fam = h.famous()
+    m = wit >= 0
+    assert np.array_equal(fam[m], exp_fam_by_event[wit[m]])
+    assert (fam[~m] == -1).all()
+    assert np.array_equal(h.consensus(), exp_cons)
+
+
+@pytest.mark.parametrize("name", FORKFREE)
+def test_hip_matches_reference_golden(pkg, name):
+    g = load_golden(name)
+    h = pkg.Hashgraph(g["n"], g["stake"])
+    run_schedule(h, g)
+    assert np.array_equal(h.heights(), g["height"])
+    assert_state_equal(h, g["round"], g["can_see"], g["witnesses"], g["famous"], g["consensus"])
+    h.close()
+
+
+def test_fork_is_refused(pkg):
+    g = load_golden("n8_s11_forks")
+    h = pkg.Hashgraph(g["n"])
+    h.append_events(g["creator"], g["self_parent"], g["other_parent"], g["t"], g["sig"])
+    with pytest.raises(pkg.SwirldHipError) as ei:
+        h.divide_rounds(0, len(g["creator"]))
+    assert ei.value.code == -95
+
+
+def oracle_run(n, stream, stake=None, chunk=None):
+    from oracle.oracle import Oracle
+    cr, sp, op, t, sig = stream
+    N = len(cr)
+    o = Oracle(n, stake)
+    ncs = []
+    chunk = chunk or N
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        o.append_events(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+        o.divide_rounds(a, b - a)
+        ncs.append(list(o.decide_fame()))
+    return o, ncs
+
+
+def hip_run(pkg, n, stream, stake=None, chunk=None):
+    cr, sp, op, t, sig = stream
+    N = len(cr)
+    h = pkg.Hashgraph(n, stake)
+    ncs = []
+    chunk = chunk or N
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        h.append_events(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+        h.divide_rounds(a, b - a)
+        ncs.append(list(h.decide_fame()))
+    return h, ncs
+
+
+CASES = [
+    # n, N, seed, mode, p0, p1, chunk
+    (4, 5000, 31, 0, 0, 0, None),          # coin rounds
+    (4, 3000, 32, 0, 0, 0, 17),            # incremental, coin rounds
+    (3, 2000, 33, 0, 0, 0, None),
+    (2, 500, 34, 0, 0, 0, None),
+    (16, 20000, 35, 0, 0, 0, None),
+    (16, 20000, 36, 2, 0.25, 0.02, 700),   # slow members, incremental (laggard restarts)
+    (40, 20000, 37, 3, 0.6, 0, None),      # stale other-parents
+    (64, 100000, 2, 0, 0, 0, None),        # BASELINE.json configs[1]
+    (64, 30000, 38, 1, 0.01, 0, 5000),     # two cliques, incremental
+    (65, 20000, 39, 0, 0, 0, None),        # first size with two mask words
+    (128, 30000, 40, 0, 0, 0, None),
+    (200, 30000, 41, 2, 0.1, 0.05, None),
+    (256, 40000, 3, 0, 0, 0, None),        # prefix of BASELINE.json configs[2]
+    (300, 30000, 42, 0, 0, 0, None),       # 8 mask words
+    (600, 30000, 43, 0, 0, 0, None),       # 16 mask words
+]
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,chunk", CASES)
+def test_hip_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk):
+    stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    o, ncs_o = oracle_run(n, stream, chunk=chunk)
+    h, ncs_h = hip_run(pkg, n, stream, chunk=chunk)
+    assert ncs_h == ncs_o
+    assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+    c, co = h.counters(), o.counters()
+    assert c["rounds"] == co["rounds"]
+    if chunk is None:
+        assert c["voter_evals"] == co["voter_evals"]
+        assert c["majority_evals"] == co["majority_evals"]
+    h.close()
+
+
+@pytest.mark.parametrize("stake", [[1] * 9 + [2], [2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2], [3, 1, 4, 1, 5, 2]])
+def test_hip_weighted_stake(pkg, stake):
+    n = len(stake)
+    stream = pkg.synth_hashgraph(n, 4000, 50 + n, 0, 0, 0)
+    st = np.array(stake, np.uint64)
+    o, ncs_o = oracle_run(n, stream, stake=st)
+    h, ncs_h = hip_run(pkg, n, stream, stake=st)
+    assert ncs_h == ncs_o
+    assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+
+
+def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
+    """Candidate-list width and band size only change the schedule, never the results
+    (exercises cursor retries and the out-of-band 'far hop' path)."""
+    n, N = 48, 15000
+    stream = pkg.synth_hashgraph(n, N, 60, 2, 0.2, 0.03)
+    o, ncs_o = oracle_run(n, stream)
+    for k, band in [("4", "64"), ("4", "100000"), ("32", "128")]:
+        monkeypatch.setenv("SW_TALLY_K", k)
+        monkeypatch.setenv("SW_BAND", band)
+        h, ncs_h = hip_run(pkg, n, stream)
+        assert ncs_h == ncs_o
+        assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+        h.close()
+
+
+def test_full_size_properties(pkg):
+    """256 members / 1M events (BASELINE.json configs[2]): properties that need no oracle.
+    (a) sees-mask self bit; (b) rounds are monotone along every self-parent chain and
+    round <= max(parent rounds)+1; (c) witness table = first event of each member per
+    round; (d) the 40k-event prefix equals a separate 40k-event run (prefix stability of
+    round / can_see / witnesses); (e) re-running gives identical results."""
+    n, N = 256, 1_000_000
+    stream = pkg.synth_hashgraph(n, N, 3, 0, 0, 0)
+    cr, sp, op, t, sig = stream
+    h, ncs = hip_run(pkg, n, stream)
+    rnd = h.rounds()
+    nr = n
+    assert (rnd[:nr] == 0).all()
+    pr = np.maximum(rnd[sp[nr:]], rnd[op[nr:]])
+    assert ((rnd[nr:] == pr) | (rnd[nr:] == pr + 1)).all()
+    wit = h.witnesses()
+    R = wit.shape[0]
+    assert R == h.max_round + 1 and R > 250
+    # witness = first event of its creator with that round, and round increased vs self-parent
+    for r in (0, 1, R // 2, R - 1):
+        for c in range(0, n, 37):
+            w = wit[r, c]
+            if w >= 0:
+                assert cr[w] == c and rnd[w] == r
+                assert sp[w] < 0 or rnd[sp[w]] < r
+    is_wit = np.zeros(N, bool)
+    is_wit[wit[wit >= 0]] = True
+    exp_wit = np.ones(N, bool)
+    exp_wit[nr:] = rnd[nr:] > rnd[sp[nr:]]
+    assert np.array_equal(is_wit, exp_wit)
+    masks = h.sees_masks(0, 5000)
+    own = (masks[np.arange(5000), cr[:5000] // 64] >> (cr[:5000] % 64).astype(np.uint64)) & np.uint64(1)
+    assert (own == 1).all()
+    # prefix stability
+    M = 40000
+    h2, _ = hip_run(pkg, n, tuple(a[:M] for a in stream))
+    assert np.array_equal(h2.rounds(), rnd[:M])
+    assert np.array_equal(h2.can_see(), h.can_see(0, M))
+    R2 = h2.max_round  # rounds below the prefix's last round have the same witnesses
+    assert np.array_equal(h2.witnesses(0, R2), wit[:R2])
+    fam = h.famous()
+    cons = h.consensus()
+    assert cons[: R - 12].all(), "all but the last few rounds must be decided"
+    assert ((fam >= 0) == (wit >= 0))[: R - 12].all()
+    # determinism
+    h3, ncs3 = hip_run(pkg, n, stream)
+    assert ncs3 == ncs and np.array_equal(h3.rounds(), rnd) and np.array_equal(h3.famous(), fam)

@@ -1,0 +1,57 @@
+"""CPU: the round-synchronous / candidate-major reformulation the HIP kernels implement
+(tests/model_bulk.py, numpy) against the sequential oracle, on fork-free goldens and on
+fresh seeded streams.  Validates the algorithm independent of any GPU."""
+import numpy as np
+import pytest
+
+import model_bulk as mb
+from conftest import golden_names, load_golden
+from oracle.oracle import Oracle
+
+BATCH = [n for n in golden_names() if n.endswith("batch") or n.endswith("cliques")
+         or n.endswith("slow") or n.endswith("stale") or n.endswith("stake")]
+BATCH = [n for n in BATCH if not n.startswith("n130") and not n.startswith("n70")]
+
+
+def check(n, cr, sp, op, sig, stake, exp, K, MCAP):
+    L, lo, _ = mb.bulk_rounds(n, cr, sp, op, stake, K=K, MCAP=MCAP)
+    rnd, S, wit = mb.finalize(n, cr, L, lo)
+    assert np.array_equal(L, exp["can_see"])
+    assert np.array_equal(rnd, exp["round"])
+    assert np.array_equal(wit, exp["witnesses"])
+    Sw = mb.voter_masks(n, L, rnd, S, wit, stake)
+    fam = np.full(wit.shape, -1, np.int8)
+    cons = np.zeros(wit.shape[0], np.uint8)
+    new_c, p2 = mb.elections(n, wit, Sw, stake, sig[:, 0] >= 128, fam, cons)
+    m = wit >= 0
+    assert np.array_equal(fam[m], exp["famous"][wit[m]])
+    assert np.array_equal(cons, exp["consensus"])
+    return new_c, p2
+
+
+@pytest.mark.parametrize("name", BATCH)
+def test_model_matches_reference_golden(name):
+    g = load_golden(name)
+    assert g["chunk"] == len(g["creator"])
+    new_c, _ = check(g["n"], g["creator"], g["self_parent"], g["other_parent"], g["sig"],
+                     g["stake"].astype(np.int64), g, K=3, MCAP=4 * g["n"])
+    assert list(new_c) == list(g["new_c_flat"])
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,K,MCAP", [
+    (4, 1500, 21, 0, 0, 0, 1, 8),
+    (9, 1500, 22, 2, 0.3, 0.02, 2, 20),
+    (20, 2500, 23, 3, 0.6, 0, 4, 50),
+    (24, 2500, 24, 1, 0.02, 0, 8, 400),
+])
+def test_model_matches_oracle(pkg, n, N, seed, mode, p0, p1, K, MCAP):
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    o = Oracle(n)
+    o.append_events(cr, sp, op, t, sig)
+    o.divide_rounds(0, N)
+    nc = o.decide_fame()
+    exp = dict(can_see=o.can_see, round=o.round, witnesses=o.witnesses(),
+               famous=o.famous_by_event, consensus=o.consensus())
+    new_c, p2 = check(n, cr, sp, op, sig, np.ones(n, np.int64), exp, K, MCAP)
+    assert list(new_c) == list(nc)
+    assert p2 == o.counters()["majority_evals"]
