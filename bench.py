@@ -110,6 +110,8 @@ def main():
     tm = h.timings()
     c1 = h.counters()
     h.set_profiling(False)
+    cdelta = {k: c1[k] - c0[k] for k in c1}
+    cdelta_far = cdelta.get("far_hops", 0)
     evals = c1["tally_evals"] - c0["tally_evals"]
     launches = max(1, tm_dr["tally_launches"])
     bytes_per_eval = 4 * n + n * n // 8 + 8  # one can_see row + n gathered n-bit masks + result
@@ -122,13 +124,13 @@ def main():
             traffic = json.load(open(tpath)).get("tally_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    cdelta = {k: c1[k] - c0[k] for k in c1}
     dr_b, df_b = algorithmic_bytes(n, cdelta, N)
     roofline = {
         "bound": "hbm", "kernel": "k_tally_candidates", "achieved": round(achieved, 2), "peak": 8000.0,
         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
         "avg_launch_us": round(avg_launch_ms * 1e3, 2), "launches": launches,
         "evals_per_launch": round(evals / launches, 1), "bytes_per_eval": bytes_per_eval,
+        "far_hops": cdelta_far,
         "path_algorithmic_GBps": round((dr_b + df_b) / (ms_per_step * 1e-3) / 1e9, 2),
         "phase_ms": {k: round(v, 3) for k, v in (("can_see", tm_dr["can_see_ms"]), ("rounds", tm_dr["rounds_ms"]),
                                                  ("tally", tm_dr["tally_ms"]), ("finalize", tm_dr["finalize_ms"]),

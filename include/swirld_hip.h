@@ -132,6 +132,7 @@ typedef struct sw_counters {
     int64_t majority_evals;      /* P2: majority() evaluations, d >= 2 (swirld.py:260)     */
     int64_t levels;              /* DAG height levels swept by the can_see kernel          */
     int64_t kernel_launches;
+    int64_t far_hops;            /* hop masks rebuilt from rows because the hop lay outside the band */
 } sw_counters;
 int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 

@@ -77,15 +77,22 @@ __global__ void k_level_scan(const int* __restrict__ cnt, int n, int* start, int
     if (tid == 0) start[n] = s_carry;
 }
 
+// desc.w packs what the ring kernel needs without further gathers:
+//   creator(e) [10 bits] | creator(op) << 10 | (seq(e) & 7) << 20 | (seq(op) & 7) << 23
+// where seq = position on the creator's self-parent chain (slot in the LDS ring).
 __global__ void k_level_scatter(const int* __restrict__ ht, const int* __restrict__ cr,
-                                const int* __restrict__ sp, const int* __restrict__ op, int first, int K,
+                                const int* __restrict__ sp, const int* __restrict__ op,
+                                const int* __restrict__ seq, int first, int K,
                                 int hmin, const int* __restrict__ start, int* cursor, int4* desc) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     int e = first + i;
     int lv = ht[e] - hmin;
     int slot = start[lv] + atomicAdd(&cursor[lv], 1);
-    desc[slot] = make_int4(e, sp[e], op[e], cr[e]);
+    const int o = op[e];
+    int w = cr[e] | ((seq[e] & 7) << 20);
+    if (o >= 0) w |= (cr[o] << 10) | ((seq[o] & 7) << 23);
+    desc[slot] = make_int4(e, sp[e], o, w);
 }
 
 // ---------------------------------------------------------------------------------
@@ -113,11 +120,108 @@ k_cansee_levels(const int4* __restrict__ desc, const int* __restrict__ lev_start
                 const int b = L[(size_t)d.z * npad + col];
                 v = a > b ? a : b;
             }
-            if (col == d.w) v = d.x;
+            if (col == (d.w & 1023)) v = d.x;
             L[(size_t)d.x * npad + col] = v;
         }
         s = t;
         __syncthreads();  // rows of this level visible to the whole workgroup
+    }
+}
+
+
+// Same computation with the recent rows kept in LDS.  Per member a ring of H row slices
+// (slot = chain position mod H); a parent row is taken from the ring when it is still
+// there (always for the self-parent, and for the other-parent unless its creator made H or
+// more events since), else from HBM/L2.  Two LDS-only barriers per level (read phase /
+// write phase); the global stores are fire-and-forget: a row can only be re-read from
+// global memory two or more levels after it was stored (the newest slot of a member is
+// always in the ring), and every wave drains its own stores at the start of the next
+// write phase, i.e. one barrier before such a read can be issued.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int CB>
+__global__ void __launch_bounds__(1024)
+k_cansee_ring(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
+              int* L, int npad, int H) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    int* ring = smem;                              // [npad][H][CB]
+    int* ring_ev = smem + (size_t)npad * H * CB;   // [npad][H]
+    const int tid = threadIdx.x;
+    const int col = tid % CB;
+    const int sub = tid / CB;
+    const int gcol = blockIdx.x * CB + col;
+    constexpr int EPB = 1024 / CB;
+    constexpr int MAXP = 4;
+    const int hm = H - 1;
+    for (int i = tid; i < npad * H; i += 1024) ring_ev[i] = -1;
+    lds_barrier();
+    int s_cur = lev_start[0];
+    int t_cur = lev_start[1];
+    int t_nxt = nlev > 1 ? lev_start[2] : t_cur;
+    int4 dcur[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = s_cur + p * EPB + sub;
+        dcur[p] = i < t_cur ? desc[i] : make_int4(-1, -1, -1, 0);
+    }
+    for (int lv = 0; lv < nlev; ++lv) {
+        // software prefetch: descriptors of the next level, level bounds two ahead
+        int4 dn[MAXP];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int i = t_cur + p * EPB + sub;
+            dn[p] = (lv + 1 < nlev && i < t_nxt) ? desc[i] : make_int4(-1, -1, -1, 0);
+        }
+        const int t_nn = lv + 2 < nlev ? lev_start[lv + 3] : t_nxt;
+        for (int base = s_cur; base < t_cur; base += EPB * MAXP) {
+            if (base != s_cur) {
+#pragma unroll
+                for (int p = 0; p < MAXP; ++p) {
+                    const int i = base + p * EPB + sub;
+                    dcur[p] = i < t_cur ? desc[i] : make_int4(-1, -1, -1, 0);
+                }
+            }
+            int v[MAXP];
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) {  // read phase
+                const int4 d = dcur[p];
+                v[p] = -1;
+                if (d.x >= 0) {
+                    const int ce = d.w & 1023;
+                    if (d.y >= 0) {
+                        const int co = (d.w >> 10) & 1023;
+                        const int ss = (((d.w >> 20) & 7) - 1) & hm;
+                        const int so = ((d.w >> 23) & 7) & hm;
+                        int a, b;
+                        if (ring_ev[ce * H + ss] == d.y) a = ring[(ce * H + ss) * CB + col];
+                        else a = __hip_atomic_load(&L[(size_t)d.y * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ring_ev[co * H + so] == d.z) b = ring[(co * H + so) * CB + col];
+                        else b = __hip_atomic_load(&L[(size_t)d.z * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v[p] = a > b ? a : b;
+                    }
+                    if (gcol == ce) v[p] = d.x;
+                }
+            }
+            lds_barrier();  // every read of the ring is done
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores of the previous pass
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) {  // write phase
+                const int4 d = dcur[p];
+                if (d.x >= 0) {
+                    const int ce = d.w & 1023;
+                    const int se = ((d.w >> 20) & 7) & hm;
+                    L[(size_t)d.x * npad + gcol] = v[p];
+                    ring[(ce * H + se) * CB + col] = v[p];
+                    if (col == 0) ring_ev[ce * H + se] = d.x;
+                }
+            }
+            lds_barrier();
+        }
+        s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) dcur[p] = dn[p];
     }
 }
 
@@ -135,50 +239,75 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
           int* lo_r, int* cur, int* unres, int* lo_next, int* pos_next,
           int* cand, const unsigned char* __restrict__ res) {
     __shared__ int s_min;
+    __shared__ int s_cnt;
     const int c = threadIdx.x;
     if (st->done) return;
     int r = st->r;
     const int iter = st->iter;
+    // independent loads first (one memory round trip instead of a dependent chain)
     const int cs = chain_start[c];
     const int clen = chain_start[c + 1] - cs;
     int un = unres[c];
+    int curc = cur[c];
+    const int lo_r1 = (r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
+    const int lo_r2 = (r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
+    const int lopos_r1 = (r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
+    int evr_now = evalround[c], evp_now = evalpos[c];
+    int mlo = st->mlo, mhi = st->mhi;
+    int found = -1;
     if (iter > 0 && un) {
-        int found = -1;
-        for (int j = 0; j < K; ++j)
-            if (res[c * K + j]) { found = j; break; }
+        for (int j = K - 1; j >= 0; --j)
+            if (res[c * K + j]) found = j;
+    }
+    int my_lo_next = SW_INF, my_pos_next = 0;
+    if (iter > 0 && un) {
         if (found >= 0) {
-            lo_next[c] = cand[c * K + found];
-            pos_next[c] = cur[c] + found;
+            my_lo_next = cand[c * K + found];
+            my_pos_next = curc + found;
+            lo_next[c] = my_lo_next;
+            pos_next[c] = my_pos_next;
             un = 0;
-        } else if (cur[c] + K >= clen) {  // chain exhausted: no round-(r+1) event of c (yet)
+        } else if (curc + K >= clen) {  // chain exhausted: no round-(r+1) event of c (yet)
             un = 0;
             evalround[c] = r;
             evalpos[c] = clen;
+            evr_now = r;
+            evp_now = clen;
         } else {
-            cur[c] += K;
+            curc += K;
         }
+    } else if (iter > 0) {
+        my_lo_next = lo_next[c];
+        my_pos_next = pos_next[c];
     }
     int nun = __syncthreads_count(un);
     int need_mask = 0, done = 0, err = 0, max_round = 0;
-    int mlo = st->mlo, mhi = st->mhi;
     if (nun == 0) {
-        if (iter > 0) {  // commit round r
-            if (lo_next[c] != SW_INF) {
-                lo[(size_t)(r + 1) * npad + c] = lo_next[c];
-                lopos[(size_t)(r + 1) * npad + c] = pos_next[c];
+        int lr, nx, start;
+        if (iter > 0) {  // commit round r, then look at round r+1
+            if (my_lo_next != SW_INF) {
+                lo[(size_t)(r + 1) * npad + c] = my_lo_next;
+                lopos[(size_t)(r + 1) * npad + c] = my_pos_next;
+                lr = my_lo_next;
+                start = my_pos_next;
+            } else {
+                lr = lo_r1;
+                start = lopos_r1;
             }
+            nx = lo_r2;
             r = r + 1;
+        } else {
+            lr = (r < Rcap) ? lo[(size_t)r * npad + c] : SW_INF;
+            start = (r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
+            nx = lo_r1;
         }
         for (;;) {  // enter the next round that has unresolved members
             if (r + 1 >= Rcap) { err = 1; done = 1; break; }
-            const int lr = lo[(size_t)r * npad + c];
-            const int nx = lo[(size_t)(r + 1) * npad + c];
             const int act = lr != SW_INF;
             un = 0;
             if (act && nx == SW_INF) {
-                int start = lopos[(size_t)r * npad + c];
-                if (evalround[c] == r && evalpos[c] > start) start = evalpos[c];
-                cur[c] = start;
+                if (evr_now == r && evp_now > start) start = evp_now;
+                curc = start;
                 un = start < clen;
             }
             const int nact = __syncthreads_count(act);
@@ -196,17 +325,29 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
                 need_mask = 1;
                 break;
             }
-            ++r;
+            ++r;  // nothing to do in this round: step to the next one (rare, incremental calls)
+            lr = nx;
+            start = (r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
+            nx = (r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
         }
     }
     unres[c] = un;
+    cur[c] = curc;
+    int live = 0;
     for (int j = 0; j < K; ++j) {
-        const int p = cur[c] + j;
-        cand[c * K + j] = (un && !done && p < clen) ? chain_ev[cs + p] : -1;
+        const int p = curc + j;
+        const int ok = un && !done && p < clen;
+        cand[c * K + j] = ok ? chain_ev[cs + p] : -1;
+        live += ok;
     }
+    if (c == 0) s_cnt = 0;
+    __syncthreads();
+    if (live) atomicAdd(&s_cnt, live);
+    __syncthreads();
     if (c == 0) {
         st->r = r; st->done = done; st->need_mask = need_mask; st->mlo = mlo; st->mhi = mhi;
         st->iter = iter + 1; st->n_unres = nun;
+        st->evals += (u64)s_cnt;
         if (done) st->max_round = max_round;
         if (err) st->err = 1;
     }
@@ -330,7 +471,165 @@ k_tally_candidates(RState* st, const int* __restrict__ cand, const int* __restri
     for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(3u * hits[j] > tot2));
     if (lane == 0) {
         res[w] = (3u * cnt > tot2) ? 1 : 0;  // count of members vs the STAKE threshold (Q2)
-        atomicAdd(&st->evals, 1ull);
+        if (nfar) atomicAdd(&st->far_hops, nfar);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
+// Unit-stake fast path of the same tally: bit-sliced ("vertical") counters.
+// A hop mask is W32 = 2*NW 32-bit words; lane l = (group g = l / W32, word w = l % W32)
+// accumulates word w of the masks of the hops h == g (mod G), G = 64 / W32, into bit-plane
+// counters with carry-save adders (one 32-bit logic op handles 32 members at once), the G
+// groups are then added with bit-sliced full adders across lanes, and "hits > 2T/3" is a
+// bit-sliced comparison whose popcount is the number of strongly-seen members.
+// W32 consecutive lanes read one 8*NW-byte mask: coalesced gathers from the L2-resident
+// band table.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void csa(uint32_t& hi, uint32_t& lo_, const uint32_t a, const uint32_t b, const uint32_t c) {
+    const uint32_t u = a ^ b;
+    hi = (a & b) | (u & c);
+    lo_ = u ^ c;
+}
+
+template <int PLT>
+__device__ __forceinline__ void ripple_add(uint32_t (&b)[PLT], uint32_t x, const int from) {
+#pragma unroll
+    for (int p = 0; p < PLT; ++p) {
+        if (p >= from) {
+            const uint32_t t = b[p] & x;
+            b[p] ^= x;
+            x = t;
+        }
+    }
+}
+
+// adds eight 1-bit-per-member words (Harley-Seal block)
+template <int PLT>
+__device__ __forceinline__ void add8(uint32_t (&b)[PLT], const uint32_t (&x)[8]) {
+    static_assert(PLT >= 4, "add8 needs at least 4 planes");
+    uint32_t twoA, twoB, twoC, twoD, fourA, fourB, eight;
+    csa(twoA, b[0], b[0], x[0], x[1]);
+    csa(twoB, b[0], b[0], x[2], x[3]);
+    csa(fourA, b[1], b[1], twoA, twoB);
+    csa(twoC, b[0], b[0], x[4], x[5]);
+    csa(twoD, b[0], b[0], x[6], x[7]);
+    csa(fourB, b[1], b[1], twoC, twoD);
+    csa(eight, b[2], b[2], fourA, fourB);
+    ripple_add<PLT>(b, eight, 3);
+}
+
+constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+
+template <int NW>
+__global__ void __launch_bounds__(256)
+k_tally_bits(RState* st, const int* __restrict__ cand, const int* __restrict__ L,
+             const int* __restrict__ cr, const int* __restrict__ sp, const int* __restrict__ lo_r,
+             const uint32_t* __restrict__ Mb32, uint32_t tot2, unsigned char* res, int npad) {
+    constexpr int W32 = 2 * NW;          // 32-bit words per mask
+    constexpr int G = 64 / W32;          // hop groups
+    constexpr int HPL = (64 * NW) / G;   // hops per lane
+    constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
+    __shared__ int s_pk[4][64 * NW];
+    if (st->done) return;
+    const int lane = lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int wv = blockIdx.x * 4 + wib;
+    const int e = cand[wv];
+    if (e < 0) {
+        if (lane == 0) res[wv] = 0;
+        return;
+    }
+    const int mlo = st->mlo, mhi = st->mhi;
+    int* pk = s_pk[wib];
+    const int ce = cr[e], spe = sp[e];
+    int thr[NW], P[NW];
+    u64 farm[NW];
+    u64 nfar = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        thr[j] = lo_r[j * 64 + lane];
+        int v = L[(size_t)e * npad + j * 64 + lane];
+        if (j * 64 + lane == ce) v = spe;  // the row BEFORE the self overwrite (Q4)
+        P[j] = v;
+        const bool valid = v >= thr[j];
+        const bool inband = valid && v < mhi;
+        pk[j * 64 + lane] = inband ? v - mlo : -1;
+        farm[j] = __ballot(valid && !inband);
+        nfar += __popcll(farm[j]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int w = lane % W32, g = lane / W32;
+    uint32_t b[PLT];
+#pragma unroll
+    for (int p = 0; p < PLT; ++p) b[p] = 0;
+    if constexpr (HPL >= 8) {
+#pragma unroll 4
+        for (int i0 = 0; i0 < HPL; i0 += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = pk[g + G * (i0 + u)];
+                x[u] = kk >= 0 ? Mb32[(size_t)kk * W32 + w] : 0u;
+            }
+            add8<PLT>(b, x);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+            const int kk = pk[g + G * i];
+            const uint32_t x = kk >= 0 ? Mb32[(size_t)kk * W32 + w] : 0u;
+            ripple_add<PLT>(b, x, 0);
+        }
+    }
+    if (nfar) {  // rare: hops outside the band, masks built from their rows on the fly
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            u64 far = farm[j];
+            while (far) {
+                const int h = __ffsll((long long)far) - 1;
+                far &= far - 1;
+                const int kf = __shfl(P[j], h);
+                uint32_t x = 0;
+#pragma unroll
+                for (int jj = 0; jj < NW; ++jj) {
+                    const int v = L[(size_t)kf * npad + jj * 64 + lane];
+                    const u64 bal = __ballot(v >= thr[jj]);
+                    if ((w >> 1) == jj) x = (uint32_t)(bal >> (32 * (w & 1)));
+                }
+                if (g == ((j * 64 + h) % G)) ripple_add<PLT>(b, x, 0);
+            }
+        }
+    }
+    // add the G groups: bit-sliced full adders across lanes
+#pragma unroll
+    for (int off = W32; off < 64; off <<= 1) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int p = 0; p < PLT; ++p) {
+            const uint32_t y = (uint32_t)__shfl_xor((int)b[p], off);
+            const uint32_t u = b[p] ^ y;
+            const uint32_t nc = (b[p] & y) | (u & carry);
+            b[p] = u ^ carry;
+            carry = nc;
+        }
+    }
+    // hits > floor(2T/3), bit-sliced, most significant plane first
+    const uint32_t t23 = tot2 / 3u;
+    uint32_t gt = 0, eq = 0xffffffffu;
+#pragma unroll
+    for (int p = PLT - 1; p >= 0; --p) {
+        const uint32_t tb = ((t23 >> p) & 1u) ? 0xffffffffu : 0u;
+        gt |= eq & b[p] & ~tb;
+        eq &= ~(b[p] ^ tb);
+    }
+    if ((t23 >> PLT) != 0) gt = 0;  // threshold beyond any possible count
+    uint32_t cnt = (g == 0) ? __popc(gt) : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    if (lane == 0) {
+        res[wv] = (3u * cnt > tot2) ? 1 : 0;  // count of members vs the STAKE threshold (Q2)
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
 }
@@ -536,6 +835,109 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
         cons[r] = 1;
     }
     if (p2) atomicAdd(&fc->majority_evals, p2);
+}
+
+
+// ---------------------------------------------------------------------------------
+// find_order (swirld.py:280-311), fork-free form.  Because "w sees x" (swirld.py:291-292:
+// can_see[w][c] is at least as high as x on creator c's chain) is inherited by every
+// ancestor of x, the set of already ordered events is ancestor-closed, i.e. a PREFIX of
+// every member's self-parent chain, and the events a decided round r newly orders on chain
+// c are the chain positions [ordered[c], q[r][c]) where q is the first position whose event
+// is no longer seen by famous witnesses holding more than half of the stake (:293).
+// ---------------------------------------------------------------------------------
+// q[ri][c] for round-list entry ri: one workgroup per entry, one thread per member c.
+__global__ void __launch_bounds__(1024)
+k_order_bounds(const int* __restrict__ fw_ev, const int* __restrict__ fw_off, const int* __restrict__ L,
+               const int* __restrict__ cr, const uint32_t* __restrict__ stake, uint32_t tot,
+               const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int npad, int* q) {
+    const int ri = blockIdx.x, c = threadIdx.x;
+    const int f0 = fw_off[ri], f1 = fw_off[ri + 1];
+    const int cs = chain_start[c], clen = chain_start[c + 1] - cs;
+    int a = 0, b = clen;  // invariant: positions < a are accepted, positions >= b are not
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        const int x = chain_ev[cs + mid];
+        uint32_t sum = 0;
+        for (int i = f0; i < f1; ++i) {
+            const int w = fw_ev[i];
+            if (L[(size_t)w * npad + c] >= x) sum += stake[cr[w]];
+        }
+        if (2u * sum > tot) a = mid + 1; else b = mid;
+    }
+    q[(size_t)ri * npad + c] = a;
+}
+
+// consensus timestamp of every newly ordered event (swirld.py:295-305): one wave per event.
+// For each famous witness w that sees x, the sample is the timestamp of the first
+// self-ancestor of w that does NOT see x, or of w's creator's root (Q11) = the predecessor,
+// on the chain of w's creator m, of the first event of m that sees x (binary search: the
+// latest-seen entry for x's creator is monotone along a chain).
+template <int MAXS>
+__global__ void __launch_bounds__(256)
+k_order_times(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, int n_acc,
+              const int* __restrict__ fw_ev, const int* __restrict__ fw_off, const int* __restrict__ L,
+              const int* __restrict__ cr, const int* __restrict__ seq, const double* __restrict__ t,
+              const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int npad,
+              double* ts, int* err) {
+    __shared__ double s_t[4][MAXS];
+    const int lane = lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 4 + wib;
+    if (idx >= n_acc) return;
+    const int x = acc_ev[idx];
+    const int ri = acc_ri[idx];
+    const int c = cr[x];
+    const int f0 = fw_off[ri], f1 = fw_off[ri + 1];
+    double* st = s_t[wib];
+    int len = 0;
+    for (int base = f0; base < f1; base += 64) {
+        const int i = base + lane;
+        bool sees = false;
+        double sample = 0.0;
+        if (i < f1) {
+            const int w = fw_ev[i];
+            if (L[(size_t)w * npad + c] >= x) {
+                sees = true;
+                const int m = cr[w];
+                const int cs = chain_start[m];
+                int lo_ = 0, hi = seq[w];  // first position p in [0, seq[w]] with L[chain_m[p]][c] >= x
+                while (lo_ < hi) {
+                    const int mid = (lo_ + hi) >> 1;
+                    if (L[(size_t)chain_ev[cs + mid] * npad + c] >= x) hi = mid; else lo_ = mid + 1;
+                }
+                const int a = chain_ev[cs + (lo_ > 0 ? lo_ - 1 : 0)];
+                sample = t[a];
+            }
+        }
+        const u64 bal = __ballot(sees);
+        if (sees) st[len + __popcll(bal & ((1ull << lane) - 1ull))] = sample;
+        len += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // order statistics len/2 and (len+1)/2 of the sorted samples by rank counting (:304-305)
+    const int k1 = len / 2, k2 = (len + 1) / 2;
+    if (k2 >= len) {  // IndexError in the reference (len == 1, only with unequal stakes)
+        if (lane == 0) { atomicExch(err, 1); ts[idx] = 0.0; }
+        return;
+    }
+    double v1 = 0.0, v2 = 0.0;
+    bool h1 = false, h2 = false;
+    for (int i = lane; i < len; i += 64) {
+        const double ti = st[i];
+        int rank = 0;
+        for (int j = 0; j < len; ++j) {
+            const double tj = st[j];
+            rank += (tj < ti) || (tj == ti && j < i);
+        }
+        if (rank == k1) { v1 = ti; h1 = true; }
+        if (rank == k2) { v2 = ti; h2 = true; }
+    }
+    const u64 b1 = __ballot(h1), b2 = __ballot(h2);
+    const int l1 = __ffsll((long long)b1) - 1, l2 = __ffsll((long long)b2) - 1;
+    const double r1 = __shfl(v1, l1), r2 = __shfl(v2, l2);
+    if (lane == 0) ts[idx] = .5 * (r1 + r2);
 }
 
 __global__ void k_fill_i32(int* p, size_t n, int v) {

@@ -39,12 +39,14 @@ struct sw_ctx {
     // host mirror of the DAG (validation, height, chains)
     std::vector<int32_t> cr, sp, op, ht;
     std::vector<int32_t> head;      // latest event per member (-1 none)
+    std::vector<int32_t> nev;       // events per member so far (next chain position)
     bool has_forks = false;
+    int max_height = 0;
     int64_t N = 0, cap = 0, divided = 0;
     bool chains_dirty = true;
 
     // device: events
-    DBuf<int32_t> d_cr, d_sp, d_op, d_ht, d_round, d_L, d_chain_ev;
+    DBuf<int32_t> d_cr, d_sp, d_op, d_ht, d_seq, d_round, d_L, d_chain_ev;
     DBuf<unsigned char> d_coin, d_sig;
     DBuf<double> d_t;
     DBuf<u64> d_S;
@@ -77,6 +79,9 @@ struct sw_ctx {
     int K = 16;        // candidates per member per tally launch
     int MCAP = 0;      // band size (events)
     int BATCH = 24;    // loop iterations between host checks
+    int cansee_impl = 1;  // 0 = global-memory levels, 1 = LDS ring
+    int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
+    int ring_H = 0;       // ring depth chosen at create (power of two)
 
     // profiling
     bool profiling = false;
@@ -84,7 +89,14 @@ struct sw_ctx {
     sw_counters ctr{};
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    std::vector<int64_t> transactions;  // reserved for find_order
+    // find_order state (swirld.py:53-57): ordered events are a prefix of every member's chain
+    std::vector<int32_t> transactions;
+    std::vector<int32_t> ord_pos;            // per member: chain positions already ordered
+    std::vector<unsigned char> sig_h;        // host copy of the signatures (whitening, sort key)
+    std::vector<int32_t> chain_start_h, chain_ev_h;
+    DBuf<int32_t> d_fw_ev, d_fw_off, d_q, d_acc_ev, d_acc_ri;
+    DBuf<double> d_ts;
+    int* d_err = nullptr;
 };
 
 namespace {
@@ -159,6 +171,7 @@ int ensure_events(sw_ctx* c, int64_t need) {
     CHK(dgrow(c, c->d_sp, nc, keep));
     CHK(dgrow(c, c->d_op, nc, keep));
     CHK(dgrow(c, c->d_ht, nc, keep));
+    CHK(dgrow(c, c->d_seq, nc, keep));
     CHK(dgrow(c, c->d_round, nc, keep));
     CHK(dgrow(c, c->d_coin, nc, keep));
     CHK(dgrow(c, c->d_t, nc, keep));
@@ -238,7 +251,9 @@ int rebuild_chains(sw_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, start.data(), (np + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     if (c->N)
         HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p, ev.data(), (size_t)c->N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->chain_start_h.swap(start);
+    c->chain_ev_h.swap(ev);
     c->chains_dirty = false;
     return SW_OK;
 }
@@ -246,8 +261,14 @@ int rebuild_chains(sw_ctx* c) {
 template <int NW>
 int launch_cansee(sw_ctx* c, int nlev) {
     constexpr int CB = 16;
-    hipLaunchKernelGGL(k_cansee_levels<CB>, dim3(c->npad / CB), dim3(1024), 0, c->stream,
-                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad);
+    if (c->cansee_impl == 1 && c->ring_H >= 1) {
+        const size_t lds = ((size_t)c->npad * c->ring_H * CB + (size_t)c->npad * c->ring_H) * sizeof(int);
+        hipLaunchKernelGGL(k_cansee_ring<CB>, dim3(c->npad / CB), dim3(1024), lds, c->stream,
+                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, c->ring_H);
+    } else {
+        hipLaunchKernelGGL(k_cansee_levels<CB>, dim3(c->npad / CB), dim3(1024), 0, c->stream,
+                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad);
+    }
     c->ctr.kernel_launches++;
     HIPCHK(c, hipGetLastError());
     return SW_OK;
@@ -278,7 +299,12 @@ int run_round_loop(sw_ctx* c, int r_start, float* tally_ms_out, int* tally_launc
                                (const RState*)c->d_state, (const int*)c->d_L.p, (const int*)c->d_cr.p,
                                (const int*)c->d_lo_r.p, c->d_Mb.p, np);
             Span s = span_begin(c);
-            if (c->unit_stake)
+            if (c->unit_stake && c->tally_impl == 1)
+                hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream,
+                                   c->d_state, (const int*)c->d_cand.p, (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                                   (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const uint32_t*)c->d_Mb.p,
+                                   tot2, c->d_res.p, np);
+            else if (c->unit_stake)
                 hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream,
                                    c->d_state, (const int*)c->d_cand.p, (const int*)c->d_L.p, (const int*)c->d_cr.p,
                                    (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
@@ -298,10 +324,13 @@ int run_round_loop(sw_ctx* c, int r_start, float* tally_ms_out, int* tally_launc
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (st.err) return fail(c, SW_ERANGE, "round table capacity exceeded (internal)");
         if (st.done) break;
-        if (launched > 64 * 1024 * 1024) return fail(c, SW_EIO, "round loop did not terminate");
+        // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
+        if ((int64_t)launched > (int64_t)c->max_height + 2 + c->N / K + 4096)
+            return fail(c, SW_EIO, "round loop did not terminate after %d iterations (r=%d)", launched, st.r);
     }
     c->R = st.max_round + 1;
     c->ctr.tally_evals += (int64_t)st.evals;
+    c->ctr.far_hops += (int64_t)st.far_hops;
     c->ctr.round_iterations += st.iter;
     if (c->profiling) {
         float ms = 0.f;
@@ -337,7 +366,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, c->stream, (const int*)c->d_ht.p, (int)first, (int)K, hmin, c->d_lev_cnt.p);
     hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)c->d_lev_cnt.p, nlev, c->d_lev_start.p, c->d_lev_cursor.p);
     hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, c->stream, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
-                       (const int*)c->d_sp.p, (const int*)c->d_op.p, (int)first, (int)K, hmin,
+                       (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)first, (int)K, hmin,
                        (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
     c->ctr.kernel_launches += 3;
     CHK(launch_cansee<NW>(c, nlev));
@@ -497,6 +526,123 @@ int get_round_rows(sw_ctx* c, const T* src, int r0, int r1, T* out, T absent) {
     return SW_OK;
 }
 
+
+template <int NW>
+int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, int64_t cap, int64_t* n_out) {
+    const int np = c->npad, n = c->n;
+    std::sort(rounds.begin(), rounds.end());  // sorted(new_c), swirld.py:283
+    rounds.erase(std::unique(rounds.begin(), rounds.end()), rounds.end());
+    const int nr = (int)rounds.size();
+    if (nr == 0) return SW_OK;
+    if (rounds.front() < 0 || rounds.back() >= c->R)
+        return fail(c, SW_ERANGE, "find_order: round outside [0, %d) (KeyError in the reference)", c->R);
+    if (c->chains_dirty) CHK(rebuild_chains(c));
+    const int rmin = rounds.front(), rmax = rounds.back();
+    std::vector<int32_t> wit((size_t)(rmax - rmin + 1) * np);
+    std::vector<signed char> fam((size_t)(rmax - rmin + 1) * np);
+    HIPCHK(c, hipMemcpyAsync(wit.data(), c->d_wit.p + (size_t)rmin * np, wit.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fam.data(), c->d_fam.p + (size_t)rmin * np, fam.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int32_t> fw_ev, fw_off(nr + 1, 0);
+    for (int i = 0; i < nr; ++i) {
+        const size_t row = (size_t)(rounds[i] - rmin) * np;
+        for (int m = 0; m < n; ++m) {
+            const int32_t w = wit[row + m];
+            if (w < 0) continue;
+            if (fam[row + m] < 0)
+                return fail(c, SW_EINVAL, "find_order: round %d has an undecided witness (KeyError on self.famous[w], swirld.py:284)", rounds[i]);
+            if (fam[row + m]) fw_ev.push_back(w);  // f_w, swirld.py:284
+        }
+        fw_off[i + 1] = (int32_t)fw_ev.size();
+    }
+    CHK(dgrow(c, c->d_fw_ev, std::max<size_t>(fw_ev.size(), 1), 0));
+    CHK(dgrow(c, c->d_fw_off, nr + 1, 0));
+    CHK(dgrow(c, c->d_q, (size_t)nr * np, 0));
+    if (!fw_ev.empty())
+        HIPCHK(c, hipMemcpyAsync(c->d_fw_ev.p, fw_ev.data(), fw_ev.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_fw_off.p, fw_off.data(), (nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_order_bounds, dim3(nr), dim3(np), 0, c->stream, (const int*)c->d_fw_ev.p, (const int*)c->d_fw_off.p,
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const uint32_t*)c->d_stake.p, c->tot,
+                       (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, np, c->d_q.p);
+    c->ctr.kernel_launches++;
+    std::vector<int32_t> q((size_t)nr * np);
+    HIPCHK(c, hipMemcpyAsync(q.data(), c->d_q.p, q.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // newly ordered chain segments per round (tbd = everything at or after ord_pos)
+    std::vector<int32_t> ord = c->ord_pos;
+    std::vector<int32_t> acc_ev, acc_ri;
+    std::vector<int64_t> acc_off(nr + 1, 0);
+    for (int i = 0; i < nr; ++i) {
+        for (int m = 0; m < n; ++m) {
+            const int hi = q[(size_t)i * np + m];
+            for (int p = ord[m]; p < hi; ++p) {
+                acc_ev.push_back(c->chain_ev_h[c->chain_start_h[m] + p]);
+                acc_ri.push_back(i);
+            }
+            if (hi > ord[m]) ord[m] = hi;
+        }
+        acc_off[i + 1] = (int64_t)acc_ev.size();
+    }
+    const int64_t n_acc = (int64_t)acc_ev.size();
+    std::vector<double> ts((size_t)n_acc);
+    if (n_acc) {
+        CHK(dgrow(c, c->d_acc_ev, n_acc, 0));
+        CHK(dgrow(c, c->d_acc_ri, n_acc, 0));
+        CHK(dgrow(c, c->d_ts, n_acc, 0));
+        HIPCHK(c, hipMemcpyAsync(c->d_acc_ev.p, acc_ev.data(), n_acc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_acc_ri.p, acc_ri.data(), n_acc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_order_times<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
+                           (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
+                           (const int*)c->d_fw_off.p, (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_seq.p,
+                           (const double*)c->d_t.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, np,
+                           c->d_ts.p, c->d_err);
+        c->ctr.kernel_launches++;
+        int err = 0;
+        HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_ts.p, n_acc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        if (err) return fail(c, SW_ERANGE, "find_order: an event is seen by a single famous witness (IndexError at swirld.py:305)");
+    }
+    // final order inside each round: (consensus timestamp, whitened signature), swirld.py:306
+    struct Item { double ts; uint64_t k8; int32_t ev; };
+    int64_t produced = 0;
+    std::vector<Item> items;
+    for (int i = 0; i < nr; ++i) {
+        unsigned char white[64] = {0};  // swirld.py:285
+        for (int j = fw_off[i]; j < fw_off[i + 1]; ++j)
+            for (int b = 0; b < 64; ++b) white[b] ^= c->sig_h[(size_t)fw_ev[j] * 64 + b];
+        items.clear();
+        for (int64_t a = acc_off[i]; a < acc_off[i + 1]; ++a) {
+            Item it{ts[a], 0, acc_ev[a]};
+            const unsigned char* sg = c->sig_h.data() + (size_t)acc_ev[a] * 64;
+            for (int b = 0; b < 8; ++b) it.k8 = (it.k8 << 8) | (unsigned char)(white[b] ^ sg[b]);
+            items.push_back(it);
+        }
+        std::sort(items.begin(), items.end(), [&](const Item& x, const Item& y) {
+            if (x.ts != y.ts) return x.ts < y.ts;
+            if (x.k8 != y.k8) return x.k8 < y.k8;
+            const unsigned char* sx = c->sig_h.data() + (size_t)x.ev * 64;
+            const unsigned char* sy = c->sig_h.data() + (size_t)y.ev * 64;
+            for (int b = 8; b < 64; ++b) {
+                const unsigned char kx = white[b] ^ sx[b], ky = white[b] ^ sy[b];
+                if (kx != ky) return kx < ky;
+            }
+            return x.ev < y.ev;
+        });
+        for (const Item& it : items) {  // swirld.py:307-309
+            c->transactions.push_back(it.ev);
+            if (out_events && produced < cap) out_events[produced] = it.ev;
+            ++produced;
+        }
+    }
+    c->ord_pos.swap(ord);
+    if (n_out) *n_out = produced;
+    if (produced > cap) return fail(c, SW_ERANGE, "find_order: out_events capacity %lld < %lld", (long long)cap, (long long)produced);
+    return SW_OK;
+}
+
 }  // namespace
 
 // ====================================================================================
@@ -540,11 +686,24 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     for (int i = 0; i < n_members; ++i) c->stake_h[i] = (uint32_t)stake[i];
     c->head.assign(n_members, -1);
     c->front.assign(n_members, -1);
+    c->ord_pos.assign(n_members, 0);
     c->lo0_h.assign(c->npad, SW_INF);
     c->MCAP = std::max(32 * c->npad, 2048);
     if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, atoi(s));
     if (const char* s = getenv("SW_BAND")) c->MCAP = std::max(64, atoi(s));
     if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
+    if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
+    if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
+    c->nev.assign(n_members, 0);
+    {
+        // LDS ring depth of the can_see kernel: largest power of two <= 8 that fits 144 KiB
+        const size_t per_slot = ((size_t)c->npad * 16 + c->npad) * sizeof(int);
+        int H = 8;
+        while (H > 1 && per_slot * H > 144u * 1024u) H >>= 1;
+        if (per_slot * H > 144u * 1024u) H = 0;
+        if (const char* s = getenv("SW_RING_H")) { int v = atoi(s); if (v >= 1 && v <= H && (v & (v - 1)) == 0) H = v; }
+        c->ring_H = H;
+    }
     c->K = (c->K + 3) & ~3;  // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway)
     auto bail = [&](int rc) { g_create_error = c->err; sw_destroy(c); return rc; };
 #define CCHK(expr) do { int rc_ = (expr); if (rc_ != SW_OK) return bail(rc_); } while (0)
@@ -553,6 +712,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CHIP(hipMalloc((void**)&c->d_state, sizeof(RState)));
     CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
+    CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
     const int np = c->npad;
     CCHK(dgrow(c, c->d_stake, np, 0));
     CHIP(hipMemcpy(c->d_stake.p, c->stake_h.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -574,6 +734,15 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(fill_i32(c, c->d_pos_next.p, np, 0));
     CHIP(hipMemsetAsync(c->d_res.p, 0, (size_t)np * c->K, c->stream));
     CCHK(ensure_rounds(c, 256));
+    if (c->ring_H >= 1) {
+        const size_t lds = ((size_t)np * c->ring_H * 16 + (size_t)np * c->ring_H) * sizeof(int);
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)k_cansee_ring<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            while (c->ring_H > 1 && ((size_t)np * c->ring_H * 17) * sizeof(int) > 48 * 1024) c->ring_H >>= 1;
+            if (((size_t)np * c->ring_H * 17) * sizeof(int) > 48 * 1024) c->cansee_impl = 0;
+        }
+    }
     CHIP(hipStreamSynchronize(c->stream));
 #undef CCHK
 #undef CHIP
@@ -585,7 +754,7 @@ int sw_destroy(sw_ctx* c) {
     if (!c) return SW_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_round); dfree(c->d_L);
+    dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
     dfree(c->d_chain_start); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
@@ -594,6 +763,8 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_pos_next); dfree(c->d_cand); dfree(c->d_res); dfree(c->d_Mb);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
+    if (c->d_err) (void)hipFree(c->d_err);
+    dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -633,15 +804,21 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     const int64_t N0 = c->N;
     c->cr.resize(N0 + K); c->sp.resize(N0 + K); c->op.resize(N0 + K); c->ht.resize(N0 + K);
     std::vector<unsigned char> coin(K);
+    std::vector<int32_t> seq(K);
     for (int64_t i = 0; i < K; ++i) {
         const int64_t e = N0 + i;
         const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
         c->cr[e] = m; c->sp[e] = s; c->op[e] = o;
         c->ht[e] = s < 0 ? 0 : std::max(c->ht[s], c->ht[o]) + 1;  // swirld.py:117-120
+        c->max_height = std::max(c->max_height, c->ht[e]);
         if (c->head[m] != s) c->has_forks = true;  // second child of s, or a second root
         c->head[m] = (int32_t)e;
+        seq[i] = c->nev[m]++;  // position on the member's self-parent chain
         coin[i] = sig64 ? (unsigned char)(sig64[64 * i] >> 7) : 0;  // swirld.py:272
     }
+    c->sig_h.resize((size_t)(N0 + K) * 64);
+    if (sig64) memcpy(c->sig_h.data() + (size_t)N0 * 64, sig64, (size_t)K * 64);
+    else memset(c->sig_h.data() + (size_t)N0 * 64, 0, (size_t)K * 64);
     c->N = N0 + K;
     c->chains_dirty = true;
     const size_t b4 = (size_t)K * sizeof(int32_t);
@@ -649,6 +826,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     HIPCHK(c, hipMemcpyAsync(c->d_sp.p + N0, c->sp.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_op.p + N0, c->op.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ht.p + N0, c->ht.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_seq.p + N0, seq.data(), b4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_coin.p + N0, coin.data(), K, hipMemcpyHostToDevice, c->stream));
     if (t) HIPCHK(c, hipMemcpyAsync(c->d_t.p + N0, t, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
     else HIPCHK(c, hipMemsetAsync(c->d_t.p + N0, 0, (size_t)K * sizeof(double), c->stream));
@@ -711,12 +889,24 @@ int sw_rewind(sw_ctx* c) {
     c->R = 0;
     c->sw_dirty_from = 1;
     c->transactions.clear();
+    std::fill(c->ord_pos.begin(), c->ord_pos.end(), 0);
     return SW_OK;
 }
 
-int sw_find_order(sw_ctx* c, const int32_t*, int, int32_t*, int64_t, int64_t* n_out) {
+int sw_find_order(sw_ctx* c, const int32_t* rounds, int n_rounds, int32_t* out_events, int64_t cap, int64_t* n_out) {
+    if (!c) return SW_EINVAL;
     if (n_out) *n_out = 0;
-    return fail(c, SW_ENOTSUP, "find_order is not implemented yet");
+    if (n_rounds < 0 || (n_rounds > 0 && !rounds)) return fail(c, SW_EINVAL, "find_order: NULL rounds");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int32_t> rs(rounds, rounds + n_rounds);
+    switch (c->nw) {
+        case 1: return do_find_order<1>(c, rs, out_events, cap, n_out);
+        case 2: return do_find_order<2>(c, rs, out_events, cap, n_out);
+        case 4: return do_find_order<4>(c, rs, out_events, cap, n_out);
+        case 8: return do_find_order<8>(c, rs, out_events, cap, n_out);
+        case 16: return do_find_order<16>(c, rs, out_events, cap, n_out);
+    }
+    return fail(c, SW_EINVAL, "unsupported member count");
 }
 
 // ---- getters ----
@@ -804,7 +994,7 @@ int sw_num_ordered(sw_ctx* c, int64_t* out) {
 int sw_get_transactions(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
     if (!c || !out) return SW_EINVAL;
     if (first < 0 || K < 0 || first + K > (int64_t)c->transactions.size()) return fail(c, SW_ERANGE, "range outside the ordered events");
-    for (int64_t i = 0; i < K; ++i) out[i] = (int32_t)c->transactions[first + i];
+    for (int64_t i = 0; i < K; ++i) out[i] = c->transactions[first + i];
     return SW_OK;
 }
 

@@ -150,6 +150,26 @@ def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize("cansee,tally,ring_h", [("0", "0", None), ("1", "0", "1"), ("1", "1", "2"), ("0", "1", None), ("1", "1", None)])
+def test_kernel_variants_agree(pkg, monkeypatch, cansee, tally, ring_h):
+    """Both can_see kernels (global-memory levels / LDS ring at several depths) and both
+    tally kernels (column-lane / bit-sliced) against the oracle, on inputs that stress the
+    ring (stale other-parents miss it; incremental batches read rows of earlier kernels)."""
+    monkeypatch.setenv("SW_CANSEE_IMPL", cansee)
+    monkeypatch.setenv("SW_TALLY_IMPL", tally)
+    if ring_h:
+        monkeypatch.setenv("SW_RING_H", ring_h)
+    for n, N, seed, mode, p0, p1, chunk in [(48, 12000, 70, 3, 0.85, 0, None), (256, 20000, 71, 3, 0.7, 0, 6000),
+                                            (20, 8000, 72, 2, 0.3, 0.01, 900), (130, 14000, 73, 0, 0, 0, None),
+                                            (5, 3000, 74, 0, 0, 0, 40)]:
+        stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+        o, ncs_o = oracle_run(n, stream, chunk=chunk)
+        h, ncs_h = hip_run(pkg, n, stream, chunk=chunk)
+        assert ncs_h == ncs_o
+        assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+        h.close()
+
+
 def test_full_size_properties(pkg):
     """256 members / 1M events (BASELINE.json configs[2]): properties that need no oracle.
     (a) sees-mask self bit; (b) rounds are monotone along every self-parent chain and
