@@ -23,11 +23,11 @@ struct RState {
     int done;       // no member has an event of round >= r: the loop is finished
     int need_mask;  // the band mask table must be (re)built for round r
     int mlo, mhi;   // band of event indices covered by the mask table
+    int mask_from;  // first band event whose mask must be (re)built in this iteration
     int iter;       // iterations executed in this call
     int n_unres;    // members still searching their first round-(r+1) event
     int max_round;  // valid when done
     int err;        // 1 = lo table capacity exceeded
-    int pad_;
     u64 evals;      // tallies evaluated (live candidates)
     u64 far_hops;   // hop masks computed on the fly (outside the band)
 };
@@ -225,6 +225,119 @@ k_cansee_ring(const int4* __restrict__ desc, const int* __restrict__ lev_start, 
     }
 }
 
+
+// Third version of the can_see sweep: LDS ring (as above) + the level descriptors streamed
+// through an LDS staging ring a chunk ahead (no global-memory latency on the per-level
+// critical path) + no per-level drain of the global stores: a workgroup-wide drain + barrier
+// is taken only in the (rare) levels where some parent row is not in the ring and has to be
+// re-read from memory.  A level holds at most one event per member (equal heights imply
+// different creators), so MAXP * (1024 / CB) >= npad covers any level in one pass.
+template <int CB, int MAXP>
+__global__ void __launch_bounds__(1024)
+k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
+                int* L, int npad, int H, int chs) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr int NS = 4;
+    const int CH = 1 << chs;  // descriptors per staging chunk (power of two, >= npad)
+    int4* dstage = (int4*)smem;                              // [NS][CH]
+    int* ring = smem + (size_t)NS * CH * 4;                  // [npad][H][CB]
+    int* ring_ev = ring + (size_t)npad * H * CB;             // [npad][H]
+    int* s_miss = ring_ev + (size_t)npad * H;                // [2]
+    const int tid = threadIdx.x;
+    const int col = tid % CB;
+    const int sub = tid / CB;
+    const int gcol = blockIdx.x * CB + col;
+    constexpr int EPB = 1024 / CB;
+    const int hm = H - 1;
+    const int total = lev_start[nlev];
+    for (int i = tid; i < npad * H; i += 1024) ring_ev[i] = -1;
+    if (tid < 2) s_miss[tid] = 0;
+    // descriptor chunks 0 and 1 resident, chunk 2 in flight in registers
+    for (int q = 0; q < 2; ++q)
+        for (int i = tid; i < CH; i += 1024) {
+            const int gi = q * CH + i;
+            dstage[(size_t)q * CH + i] = gi < total ? desc[gi] : make_int4(-1, -1, -1, 0);
+        }
+    int pend_q = 2;
+    int4 pend = make_int4(-1, -1, -1, 0);
+    if (tid < CH && pend_q * CH + tid < total) pend = desc[(size_t)pend_q * CH + tid];
+    lds_barrier();
+    int s_cur = lev_start[0];
+    int t_cur = lev_start[1];
+    int t_nxt = nlev > 1 ? lev_start[2] : t_cur;
+    int4 dcur[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = s_cur + p * EPB + sub;
+        dcur[p] = i < t_cur ? dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))] : make_int4(-1, -1, -1, 0);
+    }
+    for (int lv = 0; lv < nlev; ++lv) {
+        const int t_nn = lv + 2 < nlev ? lev_start[lv + 3] : t_nxt;
+        // make the chunks the NEXT level needs resident (written before barrier 1 below)
+        const int need_q = t_nxt > 0 ? (t_nxt - 1) >> chs : 0;
+        while (need_q >= pend_q) {
+            if (tid < CH) dstage[(size_t)(pend_q % NS) * CH + tid] = pend;
+            ++pend_q;
+            pend = make_int4(-1, -1, -1, 0);
+            if (tid < CH && (size_t)pend_q * CH + tid < (size_t)total) pend = desc[(size_t)pend_q * CH + tid];
+        }
+        if (tid == 0) s_miss[(lv + 1) & 1] = 0;
+        int a[MAXP], b[MAXP];
+        unsigned miss = 0;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {  // read phase: parents from the ring
+            const int4 d = dcur[p];
+            a[p] = -1;
+            b[p] = -1;
+            if (d.x >= 0 && d.y >= 0) {
+                const int ce = d.w & 1023;
+                const int co = (d.w >> 10) & 1023;
+                const int ss = (((d.w >> 20) & 7) - 1) & hm;
+                const int so = ((d.w >> 23) & 7) & hm;
+                if (ring_ev[ce * H + ss] == d.y) a[p] = ring[(ce * H + ss) * CB + col];
+                else miss |= 1u << (2 * p);
+                if (ring_ev[co * H + so] == d.z) b[p] = ring[(co * H + so) * CB + col];
+                else miss |= 2u << (2 * p);
+            }
+        }
+        if (miss) s_miss[lv & 1] = 1;
+        lds_barrier();  // every ring read of this level is done
+        if (s_miss[lv & 1]) {  // rare, workgroup-uniform: re-read rows from memory
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores ...
+            lds_barrier();                                     // ... before anyone re-reads
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) {
+                const int4 d = dcur[p];
+                if (miss & (1u << (2 * p)))
+                    a[p] = __hip_atomic_load(&L[(size_t)d.y * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (miss & (2u << (2 * p)))
+                    b[p] = __hip_atomic_load(&L[(size_t)d.z * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int4 dn[MAXP];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {  // write phase
+            const int4 d = dcur[p];
+            if (d.x >= 0) {
+                const int ce = d.w & 1023;
+                const int se = ((d.w >> 20) & 7) & hm;
+                int v = a[p] > b[p] ? a[p] : b[p];
+                if (gcol == ce) v = d.x;
+                L[(size_t)d.x * npad + gcol] = v;
+                ring[(ce * H + se) * CB + col] = v;
+                if (col == 0) ring_ev[ce * H + se] = d.x;
+            }
+            const int i = t_cur + p * EPB + sub;  // descriptors of the next level
+            dn[p] = (lv + 1 < nlev && i < t_nxt) ? dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))]
+                                                 : make_int4(-1, -1, -1, 0);
+        }
+        lds_barrier();
+        s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) dcur[p] = dn[p];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Round loop, step 1 (one workgroup, one thread per member): consume the results of the
 // previous tally launch, advance the per-member cursors, commit lo[r+1] when every member
@@ -319,7 +432,6 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
                 if (act) atomicMin(&s_min, lr);
                 __syncthreads();
                 mlo = s_min;
-                mhi = (N - mlo > MCAP) ? mlo + MCAP : N;
                 lo_r[c] = lr;
                 lo_next[c] = SW_INF;
                 need_mask = 1;
@@ -333,19 +445,37 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
     }
     unres[c] = un;
     cur[c] = curc;
-    int live = 0;
+    int live = 0, maxc = -1;
     for (int j = 0; j < K; ++j) {
         const int p = curc + j;
         const int ok = un && !done && p < clen;
-        cand[c * K + j] = ok ? chain_ev[cs + p] : -1;
+        const int ev = ok ? chain_ev[cs + p] : -1;
+        cand[c * K + j] = ev;
         live += ok;
+        maxc = ev > maxc ? ev : maxc;
     }
-    if (c == 0) s_cnt = 0;
+    if (c == 0) { s_cnt = 0; s_min = -1; }
     __syncthreads();
-    if (live) atomicAdd(&s_cnt, live);
+    if (live) { atomicAdd(&s_cnt, live); atomicMax(&s_min, maxc); }
     __syncthreads();
+    // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
+    // (hops beyond the cap are rebuilt from their rows by the tally kernel)
+    int mask_from = mlo;
+    {
+        int want = s_min + 1;
+        if (want - mlo > MCAP) want = mlo + MCAP;
+        if (want > N) want = N;
+        if (need_mask) {
+            mhi = want > mlo ? want : mlo;
+        } else if (!done && want > mhi) {  // retry iteration reaching further: extend the table
+            mask_from = mhi;
+            mhi = want;
+            need_mask = 1;
+        }
+    }
     if (c == 0) {
         st->r = r; st->done = done; st->need_mask = need_mask; st->mlo = mlo; st->mhi = mhi;
+        st->mask_from = mask_from;
         st->iter = iter + 1; st->n_unres = nun;
         st->evals += (u64)s_cnt;
         if (done) st->max_round = max_round;
@@ -370,7 +500,7 @@ k_band_masks(const RState* __restrict__ st, const int* __restrict__ L, const int
     int thr[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) thr[j] = lo_r[j * 64 + lane];
-    for (int k = mlo + wave; k < mhi; k += nwaves) {
+    for (int k = st->mask_from + wave; k < mhi; k += nwaves) {
         if (k < lo_r[cr[k]]) continue;  // round[k] < r: never a valid hop this round
 #pragma unroll
         for (int j = 0; j < NW; ++j) {

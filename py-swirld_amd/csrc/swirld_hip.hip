@@ -76,10 +76,11 @@ struct sw_ctx {
     int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
 
     // tuning
-    int K = 16;        // candidates per member per tally launch
+    int K = 32;        // candidates per member per tally launch
     int MCAP = 0;      // band size (events)
     int BATCH = 24;    // loop iterations between host checks
-    int cansee_impl = 1;  // 0 = global-memory levels, 1 = LDS ring
+    int cansee_impl = 2;  // 0 = global-memory levels, 1 = LDS ring, 2 = LDS ring + streamed descriptors
+    int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
 
@@ -258,10 +259,49 @@ int rebuild_chains(sw_ctx* c) {
     return SW_OK;
 }
 
+// geometry of the streaming can_see kernel for this member count
+struct CanseeCfg { int CB, MAXP, H, chs; size_t lds; };
+CanseeCfg cansee_cfg(int npad, int want_H) {
+    CanseeCfg g{};
+    g.CB = npad <= 256 ? 16 : 4;
+    const int EPB = 1024 / g.CB;
+    g.MAXP = std::max(1, npad / EPB);
+    int ch = 256;
+    g.chs = 8;
+    while (ch < npad) { ch <<= 1; g.chs++; }
+    int H = 8;
+    auto bytes = [&](int h) { return (size_t)4 * ch * 16 + ((size_t)npad * h * g.CB + (size_t)npad * h + 2) * sizeof(int); };
+    while (H > 1 && bytes(H) > 158u * 1024u) H >>= 1;
+    if (want_H >= 1 && want_H <= H && (want_H & (want_H - 1)) == 0) H = want_H;
+    g.H = H;
+    g.lds = bytes(H);
+    return g;
+}
+
+template <int CB, int MAXP>
+int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_cansee_stream<CB, MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_cansee_stream<CB, MAXP>), dim3(c->npad / CB), dim3(1024), g.lds, c->stream,
+                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, g.H, g.chs);
+    return SW_OK;
+}
+
 template <int NW>
 int launch_cansee(sw_ctx* c, int nlev) {
     constexpr int CB = 16;
-    if (c->cansee_impl == 1 && c->ring_H >= 1) {
+    if (c->cansee_impl == 2) {
+        const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req);
+        if (g.CB == 16 && g.MAXP == 1) CHK((launch_cansee_stream<16, 1>(c, nlev, g)));
+        else if (g.CB == 16 && g.MAXP == 2) CHK((launch_cansee_stream<16, 2>(c, nlev, g)));
+        else if (g.CB == 16) CHK((launch_cansee_stream<16, 4>(c, nlev, g)));
+        else if (g.MAXP == 2) CHK((launch_cansee_stream<4, 2>(c, nlev, g)));
+        else CHK((launch_cansee_stream<4, 4>(c, nlev, g)));
+    } else if (c->cansee_impl == 1 && c->ring_H >= 1) {
         const size_t lds = ((size_t)c->npad * c->ring_H * CB + (size_t)c->npad * c->ring_H) * sizeof(int);
         hipLaunchKernelGGL(k_cansee_ring<CB>, dim3(c->npad / CB), dim3(1024), lds, c->stream,
                            (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, c->ring_H);
@@ -688,7 +728,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->front.assign(n_members, -1);
     c->ord_pos.assign(n_members, 0);
     c->lo0_h.assign(c->npad, SW_INF);
-    c->MCAP = std::max(32 * c->npad, 2048);
+    c->MCAP = std::max(128 * c->npad, 8192);
     if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, atoi(s));
     if (const char* s = getenv("SW_BAND")) c->MCAP = std::max(64, atoi(s));
     if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
@@ -701,7 +741,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         int H = 8;
         while (H > 1 && per_slot * H > 144u * 1024u) H >>= 1;
         if (per_slot * H > 144u * 1024u) H = 0;
-        if (const char* s = getenv("SW_RING_H")) { int v = atoi(s); if (v >= 1 && v <= H && (v & (v - 1)) == 0) H = v; }
+        if (const char* s = getenv("SW_RING_H")) { int v = atoi(s); c->ring_H_req = v; if (v >= 1 && v <= H && (v & (v - 1)) == 0) H = v; }
         c->ring_H = H;
     }
     c->K = (c->K + 3) & ~3;  // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway)

@@ -1,0 +1,354 @@
+"""Drop-in `Node` / `Event` with the reference's API (swirld.py:30, 36-328) whose virtual
+voting — divide_rounds / decide_fame / find_order and the can_see reachability table they
+sit on — runs on the GPU through the C-ABI (include/swirld_hip.h).
+
+Same constructor, attribute names, method names, return values and call protocol as the
+reference class, so code written against `swirld.Node` (its `main()` loop, `test()`, the
+viz app that reads `round` / `famous` / `idx` / `height` / `hg`) keeps working:
+
+    Node(kp, network, n_nodes, stake)               swirld.py:38
+    new_event / is_valid_event / add_event           swirld.py:82-120   (host, unchanged role)
+    sync / ask_sync                                  swirld.py:122-161  (host, unchanged role)
+    divide_rounds(events) -> None                    swirld.py:187      -> sw_divide_rounds
+    decide_fame() -> set of rounds                   swirld.py:224      -> sw_decide_fame
+    find_order(new_c) -> None                        swirld.py:280      -> sw_find_order
+    main() generator                                 swirld.py:315
+
+State that the reference keeps in dicts keyed by 32-byte hashes lives in HBM keyed by dense
+indices; `round`, `can_see`, `witnesses`, `famous` are lazy read-only Mapping views over it
+(host glue keeps hash -> index and pk -> member maps).  The hot path has no CPU fallback.
+"""
+from collections import namedtuple
+from collections.abc import Mapping
+from pickle import dumps, loads
+from time import time
+
+import numpy as np
+
+from . import crypto
+from .engine import Hashgraph
+from .hgutils import bfs, randrange, toposort
+
+C = 6  # coin-round period, swirld.py:17
+
+
+def majority(it):
+    """Stake-weighted vote tally; a tie counts as True (swirld.py:20-27)."""
+    no = yes = 0
+    for stake, vote in it:
+        if vote:
+            yes += stake
+        else:
+            no += stake
+    return (False, no) if no > yes else (True, yes)
+
+
+Event = namedtuple("Event", "d p t c s")  # payload, parents, time, creator pk, signature
+
+
+class _RoundView(Mapping):
+    """Node.round: {event hash -> round number} (swirld.py:51-52)."""
+
+    def __init__(self, node):
+        self._n = node
+
+    def __getitem__(self, h):
+        i = self._n._index[h]
+        if i >= self._n._divided:
+            raise KeyError(h)
+        return int(self._n._rounds()[i])
+
+    def __iter__(self):
+        return iter(self._n._ids[: self._n._divided])
+
+    def __len__(self):
+        return self._n._divided
+
+
+class _CanSeeView(Mapping):
+    """Node.can_see: {event -> {member pk -> latest event of that member it sees}}
+    (swirld.py:69-72); rows are fetched from HBM on demand."""
+
+    def __init__(self, node):
+        self._n = node
+
+    def __getitem__(self, h):
+        nd = self._n
+        i = nd._index[h]
+        if i >= nd._divided:
+            raise KeyError(h)
+        row = nd._dev.can_see(i, 1)[0]
+        return {nd._members[c]: nd._ids[k] for c, k in enumerate(row) if k >= 0}
+
+    def __iter__(self):
+        return iter(self._n._ids[: self._n._divided])
+
+    def __len__(self):
+        return self._n._divided
+
+
+class _WitnessView(Mapping):
+    """Node.witnesses: {round -> {member pk -> witness hash}}; inner dicts are in
+    registration order (ascending event index), which decide_fame relies on."""
+
+    def __init__(self, node):
+        self._n = node
+
+    def _table(self):
+        return self._n._witness_table()
+
+    def __getitem__(self, r):
+        tab = self._table()
+        if not 0 <= r < tab.shape[0]:
+            return {}  # the reference's defaultdict would create an empty dict
+        row = tab[r]
+        order = [c for c in np.argsort(np.where(row >= 0, row, np.iinfo(np.int32).max), kind="stable") if row[c] >= 0]
+        return {self._n._members[c]: self._n._ids[row[c]] for c in order}
+
+    def __iter__(self):
+        return iter(range(self._table().shape[0]))
+
+    def __len__(self):
+        return self._table().shape[0]
+
+
+class _FamousView(Mapping):
+    """Node.famous: {witness hash -> bool}, decided witnesses only (swirld.py:64, 263)."""
+
+    def __init__(self, node):
+        self._n = node
+
+    def _dict(self):
+        return self._n._famous_dict()
+
+    def __getitem__(self, h):
+        return self._dict()[h]
+
+    def __iter__(self):
+        return iter(self._dict())
+
+    def __len__(self):
+        return len(self._dict())
+
+
+class Node:
+    def __init__(self, kp, network, n_nodes, stake, device=0):
+        self.pk, self.sk = kp
+        self.network = network  # {pk -> Node.ask_sync}
+        self.n = n_nodes
+        self.stake = stake
+        self.tot_stake = sum(stake.values())
+        self.min_s = 2 * self.tot_stake / 3
+
+        self.hg = {}          # {event hash -> Event}
+        self.head = None
+        self.tbd = set()      # events whose final order is not decided yet
+        self.transactions = []
+        self.idx = {}
+        self.consensus = set()
+        self.height = {}
+
+        # dense indices for the device
+        self._members = list(stake.keys())
+        if len(self._members) != n_nodes:
+            raise ValueError("stake must have one entry per member")
+        self._mindex = {pk: i for i, pk in enumerate(self._members)}
+        self._ids = []
+        self._index = {}
+        self._pending = []    # (creator, self_parent, other_parent, t, sig) not yet uploaded
+        self._uploaded = 0
+        self._divided = 0
+        self._dev = Hashgraph(n_nodes, [stake[pk] for pk in self._members], coin_period=C, device=device)
+        self._round_cache = np.zeros(0, np.int32)
+        self._wit_cache = None
+        self._fam_cache = None
+
+        self.round = _RoundView(self)
+        self.can_see = _CanSeeView(self)
+        self.witnesses = _WitnessView(self)
+        self.famous = _FamousView(self)
+
+        # the node's own root event (swirld.py:75-80)
+        h, ev = self.new_event(None, ())
+        self.add_event(h, ev)
+        self.divide_rounds((h,))
+        self.head = h
+
+    # ------------------------------------------------------------------ gossip side (host)
+    def new_event(self, d, p):
+        """Create, sign and hash a new event of this node (swirld.py:82-95)."""
+        assert p == () or len(p) == 2
+        assert p == () or self.hg[p[0]].c == self.pk   # first parent is the self-parent
+        assert p == () or self.hg[p[1]].c != self.pk   # second parent is someone else's
+        t = time()
+        s = crypto.sign_detached(dumps((d, p, t, self.pk)), self.sk)
+        ev = Event(d, p, t, self.pk, s)
+        return crypto.generichash(dumps(ev)), ev
+
+    def is_valid_event(self, h, ev):
+        """Signature, hash and parent checks (swirld.py:97-108)."""
+        try:
+            crypto.verify_detached(ev.s, dumps(ev[:-1]), ev.c)
+        except ValueError:
+            return False
+        return (crypto.generichash(dumps(ev)) == h
+                and (ev.p == ()
+                     or (len(ev.p) == 2
+                         and ev.p[0] in self.hg and ev.p[1] in self.hg
+                         and self.hg[ev.p[0]].c == ev.c
+                         and self.hg[ev.p[1]].c != ev.c)))
+
+    def add_event(self, h, ev):
+        """Store an event (swirld.py:114-120); it is uploaded with the next divide_rounds."""
+        self.hg[h] = ev
+        self.tbd.add(h)
+        self.height[h] = 0 if ev.p == () else max(self.height[p] for p in ev.p) + 1
+        self._index[h] = len(self._ids)
+        self._ids.append(h)
+        sp, op = (-1, -1) if ev.p == () else (self._index[ev.p[0]], self._index[ev.p[1]])
+        self._pending.append((self._mindex[ev.c], sp, op, float(ev.t), ev.s))
+
+    def sync(self, pk, payload):
+        """Pull-sync with `pk`; returns the new event ids in topological order
+        (swirld.py:122-146)."""
+        known = {c: self.height[h] for c, h in self.can_see[self.head].items()}
+        msg = crypto.sign_open(self.network[pk](self.pk, crypto.sign(dumps(known), self.sk)), pk)
+        remote_head, remote_hg = loads(msg)
+        fresh = remote_hg.keys() - self.hg.keys()
+        new = tuple(toposort(fresh, lambda u: remote_hg[u].p))
+        for h in new:
+            ev = remote_hg[h]
+            if self.is_valid_event(h, ev):
+                self.add_event(h, ev)
+        if self.is_valid_event(remote_head, remote_hg[remote_head]):
+            h, ev = self.new_event(payload, (self.head, remote_head))
+            assert self.is_valid_event(h, ev)
+            self.add_event(h, ev)
+            self.head = h
+        return new + (h,)
+
+    def ask_sync(self, pk, info):
+        """Answer a sync request: everything the asker cannot know yet (swirld.py:148-161)."""
+        cs = loads(crypto.sign_open(info, pk))
+        subset = {h: self.hg[h] for h in bfs(
+            (self.head,),
+            lambda u: (p for p in self.hg[u].p
+                       if self.hg[p].c not in cs or self.height[p] > cs[self.hg[p].c]))}
+        return crypto.sign(dumps((self.head, subset)), self.sk)
+
+    def ancestors(self, c):
+        """Self-parent chain of c, newest first (swirld.py:163-168)."""
+        while True:
+            yield c
+            if not self.hg[c].p:
+                return
+            c = self.hg[c].p[0]
+
+    def higher(self, a, b):
+        return a is not None and (b is None or self.height[a] >= self.height[b])
+
+    def maxi(self, a, b):
+        return a if self.higher(a, b) else b
+
+    # ------------------------------------------------------------------ virtual voting (GPU)
+    def _flush(self):
+        if self._pending:
+            cr, sp, op, t, sig = zip(*self._pending)
+            self._dev.append_events(np.array(cr, np.int32), np.array(sp, np.int32), np.array(op, np.int32),
+                                    np.array(t, np.float64),
+                                    np.frombuffer(b"".join(sig), np.uint8).reshape(len(sig), 64))
+            self._uploaded += len(self._pending)
+            self._pending = []
+
+    def divide_rounds(self, events):
+        """Assign rounds / witnesses / can_see rows to the new events (swirld.py:187-222).
+        `events` must be the not-yet-divided events in the order they were added (which is
+        what sync() returns and main() passes)."""
+        events = tuple(events)
+        if not events:
+            return
+        first = self._divided
+        expect = self._ids[first:first + len(events)]
+        if list(events) != expect:
+            for h in events:
+                if h not in self.hg:
+                    raise KeyError(h)
+            raise ValueError("divide_rounds expects the undivided events in the order they were added")
+        self._flush()
+        self._dev.divide_rounds(first, len(events))
+        self._divided = first + len(events)
+        self._wit_cache = None
+
+    def decide_fame(self):
+        """Run the witness elections; returns the set of newly decided rounds
+        (swirld.py:224-277)."""
+        new_c = {int(r) for r in self._dev.decide_fame()}
+        self.consensus |= new_c
+        self._fam_cache = None
+        return new_c
+
+    def find_order(self, new_c):
+        """Extend the total order with the events the newly decided rounds receive
+        (swirld.py:280-311)."""
+        order = self._dev.find_order(new_c)
+        final = [self._ids[i] for i in order]
+        for i, x in enumerate(final):
+            self.idx[x] = i + len(self.transactions)
+        self.tbd.difference_update(final)
+        self.transactions += final
+        if self.consensus:
+            print(self.consensus)
+
+    def main(self):
+        """Main working loop: `payload = yield new_event_ids` (swirld.py:315-328)."""
+        new = ()
+        while True:
+            payload = (yield new)
+            c = tuple(self.network.keys() - {self.pk})[randrange(self.n - 1)]
+            new = self.sync(c, payload)
+            self.divide_rounds(new)
+            new_c = self.decide_fame()
+            self.find_order(new_c)
+
+    # ------------------------------------------------------------------ view plumbing
+    def _rounds(self):
+        have = self._round_cache.shape[0]
+        if have < self._divided:
+            self._round_cache = np.concatenate([self._round_cache, self._dev.rounds(have, self._divided - have)])
+        return self._round_cache
+
+    def _witness_table(self):
+        if self._wit_cache is None:
+            self._wit_cache = self._dev.witnesses()
+        return self._wit_cache
+
+    def _famous_dict(self):
+        if self._fam_cache is None:
+            wit, fam = self._witness_table(), self._dev.famous()
+            d = {}
+            for r in range(wit.shape[0]):
+                row = wit[r]
+                for c in np.argsort(np.where(row >= 0, row, np.iinfo(np.int32).max), kind="stable"):
+                    if row[c] >= 0 and fam[r, c] >= 0:
+                        d[self._ids[row[c]]] = bool(fam[r, c])
+            self._fam_cache = d
+        return self._fam_cache
+
+
+def test(n_nodes, n_turns, device=0):
+    """The reference's simulation driver (swirld.py:331-345): n_nodes nodes sharing an
+    in-process 'network', stepped at random."""
+    kps = [crypto.sign_keypair() for _ in range(n_nodes)]
+    network = {}
+    stake = {kp[0]: 1 for kp in kps}
+    nodes = [Node(kp, network, n_nodes, stake, device=device) for kp in kps]
+    for n in nodes:
+        network[n.pk] = n.ask_sync
+    mains = [n.main() for n in nodes]
+    for m in mains:
+        next(m)
+    for i in range(n_turns):
+        r = randrange(n_nodes)
+        print("working node: %i, event number: %i" % (r, i))
+        next(mains[r])
+    return nodes

@@ -27,6 +27,12 @@ def load_golden(name):
         g = {k: z[k] for k in z.files}
     g["n"] = int(g["n"])
     g["chunk"] = int(g["chunk"])
+    N = len(g["creator"])
+    if "sched" in g:  # variable batch sizes (the reference's own main loop)
+        ends = np.cumsum(g["sched"])
+        g["batches"] = [(int(e - k), int(e)) for k, e in zip(g["sched"], ends)]
+    else:
+        g["batches"] = [(a, min(N, a + g["chunk"])) for a in range(0, N, g["chunk"])]
     off = g["wit_order_off"]
     g["wit_order"] = [g["wit_order_flat"][off[i]:off[i + 1]] for i in range(len(off) - 1)]
     return g

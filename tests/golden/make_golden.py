@@ -80,6 +80,90 @@ def run_case(n, stream, stake, chunk):
         tx_off=np.array(tx_off, np.int64))
 
 
+def run_mainloop_case(n_nodes, n_turns, seed):
+    """BASELINE.json configs[0]: the reference's own simulation swirld.test(n_nodes, n_turns)
+    (swirld.py:331-345) with its real gossip, Ed25519 signatures and main() loop, made
+    deterministic (seeded libsodium RNG stand-in, counter clock).  Records, for node 0, the
+    event stream in the order it was added, the batch sizes its main loop passed to
+    divide_rounds, and all resulting state."""
+    import contextlib
+    import io
+    import random
+    import refharness
+    sw = refharness.import_reference()
+    import pysodium
+    import utils as ref_utils
+    rng = random.Random(seed)
+    pysodium.set_rng(lambda k: bytes(rng.getrandbits(8) for _ in range(k)))
+    clock = [0.0]
+
+    def fake_time():
+        clock[0] += 1.0
+        return clock[0]
+    old_time, old_rb = sw.time, ref_utils.randombytes
+    sw.time = fake_time
+    ref_utils.randombytes = pysodium.randombytes
+    sched = {}
+    orig_dr = sw.Node.divide_rounds
+    orig_df = sw.Node.decide_fame
+    orig_fo = sw.Node.find_order
+    newc_log, tx_log = {}, {}
+
+    def dr(self, events):
+        events = tuple(events)
+        sched.setdefault(id(self), []).append(len(events))
+        return orig_dr(self, events)
+
+    def df(self):
+        out = orig_df(self)
+        newc_log.setdefault(id(self), []).append(sorted(out))
+        return out
+
+    def fo(self, new_c):
+        orig_fo(self, new_c)
+        tx_log.setdefault(id(self), []).append(len(self.transactions))
+    sw.Node.divide_rounds, sw.Node.decide_fame, sw.Node.find_order = dr, df, fo
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            nodes = sw.test(n_nodes, n_turns)
+    finally:
+        sw.Node.divide_rounds, sw.Node.decide_fame, sw.Node.find_order = orig_dr, orig_df, orig_fo
+        sw.time, ref_utils.randombytes = old_time, old_rb
+        pysodium.set_rng(None)
+    node = nodes[0]
+    ids = list(node.hg.keys())            # dict order == add order
+    index = {h: i for i, h in enumerate(ids)}
+    members = list(node.stake.keys())
+    mindex = {pk: i for i, pk in enumerate(members)}
+    N = len(ids)
+    cr = np.array([mindex[node.hg[h].c] for h in ids], np.int32)
+    sp = np.array([index[node.hg[h].p[0]] if node.hg[h].p else -1 for h in ids], np.int32)
+    op = np.array([index[node.hg[h].p[1]] if node.hg[h].p else -1 for h in ids], np.int32)
+    t = np.array([node.hg[h].t for h in ids], np.float64)
+    sig = np.frombuffer(b"".join(node.hg[h].s for h in ids), np.uint8).reshape(N, 64).copy()
+    # re-express the state through a RefRun-like extraction
+    rr = RefRun.__new__(RefRun)
+    rr.node, rr.n, rr.ids, rr.id_index, rr.pk_index = node, n_nodes, ids, index, mindex
+    ex = rr.extract()
+    batches = [1] + sched[id(node)]       # the root is set up by __init__ (swirld.py:75-80)
+    assert sum(batches) == N
+    new_c_flat, new_c_off, tx_off = [], [0, 0], [0, 0]  # call 0 = the root, no fame/order call
+    for nc, ntx in zip(newc_log[id(node)], tx_log[id(node)]):
+        new_c_flat += nc
+        new_c_off.append(len(new_c_flat))
+        tx_off.append(ntx)
+    wo_flat = np.concatenate(ex["wit_order"]) if ex["wit_order"] else np.zeros(0, np.int32)
+    wo_off = np.cumsum([0] + [len(o) for o in ex["wit_order"]]).astype(np.int32)
+    return dict(
+        n=np.int32(n_nodes), stake=np.ones(n_nodes, np.uint64), chunk=np.int64(0),
+        sched=np.array(batches, np.int64), creator=cr, self_parent=sp, other_parent=op, t=t, sig=sig,
+        round=ex["round"], height=ex["height"], can_see=ex["can_see"], witnesses=ex["witnesses"],
+        wit_order_flat=wo_flat.astype(np.int32), wit_order_off=wo_off, famous=ex["famous"],
+        consensus=ex["consensus"], votes=ex["votes"], transactions=ex["transactions"], tbd=ex["tbd"],
+        new_c_flat=np.array(new_c_flat, np.int32), new_c_off=np.array(new_c_off, np.int32),
+        tx_off=np.array(tx_off, np.int64))
+
+
 def add_forks(stream, n, seed, n_forks):
     """Append forked events: same creator and self-parent as an existing event, other
     other-parent.  The reference accepts these (no fork detection, README.md:84)."""
@@ -112,6 +196,13 @@ def main():
         print("%-28s R=%3d consensus=%3d tx=%5d votes=%6d  %6.1f KB" % (
             name, out["witnesses"].shape[0], int(out["consensus"].sum()),
             len(out["transactions"]), len(out["votes"]), os.path.getsize(path) / 1024))
+    # configs[0]: the reference's own main loop (4 members, 1000 turns), node 0's view
+    out = run_mainloop_case(4, 1000, 12345)
+    path = os.path.join(HERE, "n4_mainloop_node0.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s N=%d R=%3d consensus=%3d tx=%5d calls=%d" % (
+        "n4_mainloop_node0", len(out["creator"]), out["witnesses"].shape[0], int(out["consensus"].sum()),
+        len(out["transactions"]), len(out["sched"])))
     # forked DAG (oracle-only parity: the bulk HIP path refuses forks)
     base = synth(8, 500, 11, 0, 0, 0)
     stream = add_forks(base, 8, 11, 6)

@@ -1,0 +1,50 @@
+"""GPU (-m gpu): find_order (swirld.py:280-311) through the C-ABI against the goldens of
+the unmodified reference (transactions per call, recorded schedule) and against the oracle
+on fresh streams."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FORKFREE = [n for n in golden_names() if "forks" not in n]
+
+
+@pytest.mark.parametrize("name", FORKFREE)
+def test_find_order_matches_reference_golden(pkg, name):
+    g = load_golden(name)
+    h = pkg.Hashgraph(g["n"], g["stake"])
+    calls = 0
+    for a, b in g["batches"]:
+        h.append_events(g["creator"][a:b], g["self_parent"][a:b], g["other_parent"][a:b], g["t"][a:b], g["sig"][a:b])
+        h.divide_rounds(a, b - a)
+        nc = h.decide_fame()
+        tx = h.find_order(nc)
+        exp = g["transactions"][g["tx_off"][calls]:g["tx_off"][calls + 1]]
+        assert list(tx) == list(exp), "find_order of call %d" % calls
+        calls += 1
+    assert np.array_equal(h.transactions(), g["transactions"])
+    h.close()
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,chunk", [
+    (4, 4000, 81, 0, 0, 0, 9), (16, 12000, 82, 2, 0.25, 0.03, 500), (64, 40000, 83, 0, 0, 0, None),
+    (64, 20000, 84, 3, 0.6, 0, 3000), (130, 20000, 85, 0, 0, 0, None), (256, 30000, 86, 0, 0, 0, 10000),
+])
+def test_find_order_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk):
+    from oracle.oracle import Oracle
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    t = t + (np.arange(N) % 7) * 0.25  # non-monotone timestamps with ties in the medians
+    o, h = Oracle(n), pkg.Hashgraph(n)
+    chunk = chunk or N
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        for d in (o, h):
+            d.append_events(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+            d.divide_rounds(a, b - a)
+        nco, nch = o.decide_fame(), h.decide_fame()
+        assert list(nco) == list(nch)
+        assert list(h.find_order(nch)) == list(o.find_order(nco))
+    assert np.array_equal(h.transactions(), o.transactions)
+    h.close()

@@ -16,10 +16,8 @@ FORKFREE = [n for n in golden_names() if "forks" not in n]
 
 
 def run_schedule(h, g):
-    N, chunk = len(g["creator"]), g["chunk"]
     calls = 0
-    for a in range(0, N, chunk):
-        b = min(N, a + chunk)
+    for a, b in g["batches"]:
         h.append_events(g["creator"][a:b], g["self_parent"][a:b], g["other_parent"][a:b],
                         g["t"][a:b], g["sig"][a:b])
         h.divide_rounds(a, b - a)

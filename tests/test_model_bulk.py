@@ -32,7 +32,7 @@ def check(n, cr, sp, op, sig, stake, exp, K, MCAP):
 @pytest.mark.parametrize("name", BATCH)
 def test_model_matches_reference_golden(name):
     g = load_golden(name)
-    assert g["chunk"] == len(g["creator"])
+    assert len(g["batches"]) == 1
     new_c, _ = check(g["n"], g["creator"], g["self_parent"], g["other_parent"], g["sig"],
                      g["stake"].astype(np.int64), g, K=3, MCAP=4 * g["n"])
     assert list(new_c) == list(g["new_c_flat"])

@@ -13,10 +13,8 @@ from oracle.oracle import Oracle
 def replay(driver, g, with_order=True):
     """Feeds fixture g to `driver` (Oracle-like API) with the recorded call schedule and
     checks the per-call return values of decide_fame / find_order."""
-    N, chunk = len(g["creator"]), g["chunk"]
     calls = 0
-    for a in range(0, N, chunk):
-        b = min(N, a + chunk)
+    for a, b in g["batches"]:
         driver.append_events(g["creator"][a:b], g["self_parent"][a:b], g["other_parent"][a:b],
                              g["t"][a:b], g["sig"][a:b])
         driver.divide_rounds(a, b - a)
