@@ -78,7 +78,7 @@ __global__ void k_level_scan(const int* __restrict__ cnt, int n, int* start, int
 }
 
 // desc.w packs what the ring kernel needs without further gathers:
-//   creator(e) [10 bits] | creator(op) << 10 | (seq(e) & 7) << 20 | (seq(op) & 7) << 23
+//   creator(e) [10 bits] | creator(op) << 10 | (seq(e) & 63) << 20 | (seq(op) & 63) << 26
 // where seq = position on the creator's self-parent chain (slot in the LDS ring).
 __global__ void k_level_scatter(const int* __restrict__ ht, const int* __restrict__ cr,
                                 const int* __restrict__ sp, const int* __restrict__ op,
@@ -90,8 +90,8 @@ __global__ void k_level_scatter(const int* __restrict__ ht, const int* __restric
     int lv = ht[e] - hmin;
     int slot = start[lv] + atomicAdd(&cursor[lv], 1);
     const int o = op[e];
-    int w = cr[e] | ((seq[e] & 7) << 20);
-    if (o >= 0) w |= (cr[o] << 10) | ((seq[o] & 7) << 23);
+    int w = cr[e] | ((seq[e] & 63) << 20);
+    if (o >= 0) w |= (cr[o] << 10) | ((seq[o] & 63) << 26);
     desc[slot] = make_int4(e, sp[e], o, w);
 }
 
@@ -192,8 +192,8 @@ k_cansee_ring(const int4* __restrict__ desc, const int* __restrict__ lev_start, 
                     const int ce = d.w & 1023;
                     if (d.y >= 0) {
                         const int co = (d.w >> 10) & 1023;
-                        const int ss = (((d.w >> 20) & 7) - 1) & hm;
-                        const int so = ((d.w >> 23) & 7) & hm;
+                        const int ss = (((d.w >> 20) & 63) - 1) & hm;
+                        const int so = ((d.w >> 26) & 63) & hm;
                         int a, b;
                         if (ring_ev[ce * H + ss] == d.y) a = ring[(ce * H + ss) * CB + col];
                         else a = __hip_atomic_load(&L[(size_t)d.y * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -211,7 +211,7 @@ k_cansee_ring(const int4* __restrict__ desc, const int* __restrict__ lev_start, 
                 const int4 d = dcur[p];
                 if (d.x >= 0) {
                     const int ce = d.w & 1023;
-                    const int se = ((d.w >> 20) & 7) & hm;
+                    const int se = ((d.w >> 20) & 63) & hm;
                     L[(size_t)d.x * npad + gcol] = v[p];
                     ring[(ce * H + se) * CB + col] = v[p];
                     if (col == 0) ring_ev[ce * H + se] = d.x;
@@ -232,13 +232,13 @@ k_cansee_ring(const int4* __restrict__ desc, const int* __restrict__ lev_start, 
 // is taken only in the (rare) levels where some parent row is not in the ring and has to be
 // re-read from memory.  A level holds at most one event per member (equal heights imply
 // different creators), so MAXP * (1024 / CB) >= npad covers any level in one pass.
-template <int CB, int MAXP>
-__global__ void __launch_bounds__(1024)
+template <int CB, int MAXP, int BT>
+__global__ void __launch_bounds__(BT)
 k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
                 int* L, int npad, int H, int chs) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int NS = 4;
-    const int CH = 1 << chs;  // descriptors per staging chunk (power of two, >= npad)
+    const int CH = 1 << chs;  // descriptors per staging chunk (power of two, npad <= CH <= BT)
     int4* dstage = (int4*)smem;                              // [NS][CH]
     int* ring = smem + (size_t)NS * CH * 4;                  // [npad][H][CB]
     int* ring_ev = ring + (size_t)npad * H * CB;             // [npad][H]
@@ -246,15 +246,19 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     const int tid = threadIdx.x;
     const int col = tid % CB;
     const int sub = tid / CB;
-    const int gcol = blockIdx.x * CB + col;
-    constexpr int EPB = 1024 / CB;
+    // XCD-aware column groups: workgroup b runs on XCD b % 8 (observed); give each XCD a
+    // contiguous run of column groups so that its L2 assembles whole 128-byte lines of a row
+    const int nblk = gridDim.x;
+    const int grp = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int gcol = grp * CB + col;
+    constexpr int EPB = BT / CB;
     const int hm = H - 1;
     const int total = lev_start[nlev];
-    for (int i = tid; i < npad * H; i += 1024) ring_ev[i] = -1;
+    for (int i = tid; i < npad * H; i += BT) ring_ev[i] = -1;
     if (tid < 2) s_miss[tid] = 0;
     // descriptor chunks 0 and 1 resident, chunk 2 in flight in registers
     for (int q = 0; q < 2; ++q)
-        for (int i = tid; i < CH; i += 1024) {
+        for (int i = tid; i < CH; i += BT) {
             const int gi = q * CH + i;
             dstage[(size_t)q * CH + i] = gi < total ? desc[gi] : make_int4(-1, -1, -1, 0);
         }
@@ -273,6 +277,8 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     }
     for (int lv = 0; lv < nlev; ++lv) {
         const int t_nn = lv + 2 < nlev ? lev_start[lv + 3] : t_nxt;
+        const int n_cur = t_cur - s_cur;   // events in this level (uniform)
+        const int n_nxt = t_nxt - t_cur;   // events in the next level
         // make the chunks the NEXT level needs resident (written before barrier 1 below)
         const int need_q = t_nxt > 0 ? (t_nxt - 1) >> chs : 0;
         while (need_q >= pend_q) {
@@ -286,18 +292,20 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
         unsigned miss = 0;
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {  // read phase: parents from the ring
-            const int4 d = dcur[p];
             a[p] = -1;
             b[p] = -1;
-            if (d.x >= 0 && d.y >= 0) {
-                const int ce = d.w & 1023;
-                const int co = (d.w >> 10) & 1023;
-                const int ss = (((d.w >> 20) & 7) - 1) & hm;
-                const int so = ((d.w >> 23) & 7) & hm;
-                if (ring_ev[ce * H + ss] == d.y) a[p] = ring[(ce * H + ss) * CB + col];
-                else miss |= 1u << (2 * p);
-                if (ring_ev[co * H + so] == d.z) b[p] = ring[(co * H + so) * CB + col];
-                else miss |= 2u << (2 * p);
+            if (p * EPB < n_cur) {  // uniform: skip passes this level does not need
+                const int4 d = dcur[p];
+                if (d.x >= 0 && d.y >= 0) {
+                    const int ce = d.w & 1023;
+                    const int co = (d.w >> 10) & 1023;
+                    const int ss = (((d.w >> 20) & 63) - 1) & hm;
+                    const int so = ((d.w >> 26) & 63) & hm;
+                    if (ring_ev[ce * H + ss] == d.y) a[p] = ring[(ce * H + ss) * CB + col];
+                    else miss |= 1u << (2 * p);
+                    if (ring_ev[co * H + so] == d.z) b[p] = ring[(co * H + so) * CB + col];
+                    else miss |= 2u << (2 * p);
+                }
             }
         }
         if (miss) s_miss[lv & 1] = 1;
@@ -317,24 +325,279 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
         int4 dn[MAXP];
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {  // write phase
-            const int4 d = dcur[p];
-            if (d.x >= 0) {
-                const int ce = d.w & 1023;
-                const int se = ((d.w >> 20) & 7) & hm;
-                int v = a[p] > b[p] ? a[p] : b[p];
-                if (gcol == ce) v = d.x;
-                L[(size_t)d.x * npad + gcol] = v;
-                ring[(ce * H + se) * CB + col] = v;
-                if (col == 0) ring_ev[ce * H + se] = d.x;
+            if (p * EPB < n_cur) {
+                const int4 d = dcur[p];
+                if (d.x >= 0) {
+                    const int ce = d.w & 1023;
+                    const int se = ((d.w >> 20) & 63) & hm;
+                    int v = a[p] > b[p] ? a[p] : b[p];
+                    if (gcol == ce) v = d.x;
+                    L[(size_t)d.x * npad + gcol] = v;
+                    ring[(ce * H + se) * CB + col] = v;
+                    if (col == 0) ring_ev[ce * H + se] = d.x;
+                }
             }
-            const int i = t_cur + p * EPB + sub;  // descriptors of the next level
-            dn[p] = (lv + 1 < nlev && i < t_nxt) ? dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))]
-                                                 : make_int4(-1, -1, -1, 0);
+            dn[p] = make_int4(-1, -1, -1, 0);
+            if (p * EPB < n_nxt) {  // descriptors of the next level
+                const int i = t_cur + p * EPB + sub;
+                if (i < t_nxt) dn[p] = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
+            }
         }
         lds_barrier();
         s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn;
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) dcur[p] = dn[p];
+    }
+}
+
+
+// Fourth version: one THREAD per member, one COLUMN per workgroup (npad workgroups, so every
+// CU sweeps the DAG for a few columns), plus one LOADER wave per workgroup.
+//  * A level holds at most one event per member, so worker thread m simply waits for "its"
+//    event of the level; the row value of m's previous event (the self-parent) stays in a
+//    register, the other-parent's value comes from an LDS ring of {event id, value} pairs.
+//    Per level: ~2 LDS round trips and two barriers of (npad/64 + 1) waves.
+//  * Wave specialisation: the loader wave streams the level descriptors and the level bounds
+//    from HBM into LDS rings far ahead of their use and never stores; the worker waves only
+//    store (fire-and-forget row values) and never load in steady state.  Loads and stores
+//    share one in-order counter (vmcnt) per wave on gfx950, so keeping them in different waves
+//    is what keeps every wait off the per-level critical path.
+//  * A ring miss (other-parent older than H events of its creator, or from an earlier batch)
+//    takes a workgroup-wide drain + barrier + re-read path (rare).
+template <int PENDL>
+__global__ void __launch_bounds__(320)
+k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
+                const int* __restrict__ prev_head, int* L, int npad, int H, int chs) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr int NS = 4;     // descriptor chunks resident
+    constexpr int LVR = 256;  // level-bound ring entries
+    const int CH = 1 << chs;  // descriptors per chunk = 64 * PENDL
+    int4* dstage = (int4*)smem;                                   // [NS][CH]
+    int4* mbox = dstage + (size_t)NS * CH;                        // [2][npad]
+    u64* ring = (u64*)(mbox + 2 * (size_t)npad);                  // [npad][H] {value << 32 | id}
+    int* lvb = (int*)(ring + (size_t)npad * H);                   // [LVR] lev_start ring
+    int* s_miss = lvb + LVR;                                      // [2]
+    const int tid = threadIdx.x;
+    const int BT = blockDim.x;            // npad workers + 64 loader lanes
+    const bool loader = tid >= npad;
+    const int m = tid;                    // member handled by a worker thread
+    const int ll = tid - npad;            // loader lane
+    const int nblk = gridDim.x;
+    const int col = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int hm = H - 1;
+    const int total = lev_start[nlev];
+    // ---- prologue (everybody helps)
+    for (int i = tid; i < npad * H; i += BT) ring[i] = 0xffffffffffffffffull;  // id -1: empty
+    for (int i = tid; i < 2 * npad; i += BT) mbox[i] = make_int4(-1, -1, -1, 0);
+    if (tid < 2) s_miss[tid] = 0;
+    for (int i = tid; i < 2 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
+    for (int i = tid; i < 128; i += BT) lvb[i] = lev_start[i < nlev ? i : nlev];
+    int pend_q = 2;       // loader: next descriptor chunk to make resident (held in pend[])
+    int4 pend[PENDL];
+    int lpend = 0;        // loader: level bounds [lv+128, lv+192) in flight
+    int mine = -1;        // worker: row value of the member's latest event
+    if (loader) {
+#pragma unroll
+        for (int k = 0; k < PENDL; ++k) {
+            const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
+            pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
+        }
+        const int j = 128 + ll;
+        lpend = lev_start[j < nlev ? j : nlev];
+    } else {
+        const int ph = prev_head[m];
+        if (ph >= 0) mine = L[(size_t)ph * npad + col];
+    }
+    lds_barrier();
+    int t_cur = lvb[1], t_nxt = lvb[2 & (LVR - 1)];
+    if (!loader) {  // mailbox of level 0
+        for (int i = lvb[0] + m; i < t_cur; i += npad) {
+            const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
+            mbox[dd.w & 1023] = dd;
+        }
+    }
+    lds_barrier();
+    for (int lv = 0; lv < nlev; ++lv) {
+        const int t_nn = lvb[(lv + 3) & (LVR - 1)];  // end of level lv+2 (clamped entries = total)
+        int4* box = mbox + (size_t)(lv & 1) * npad;
+        int4* nbox = mbox + (size_t)((lv + 1) & 1) * npad;
+        int4 d = make_int4(-1, -1, -1, 0);
+        int other = -1;
+        bool miss = false;
+        if (loader) {
+            // descriptor chunks needed by the mailbox scatter of the NEXT level, one level early
+            const int need_q = t_nn > 0 ? (t_nn - 1) >> chs : 0;
+            while (need_q + 1 >= pend_q) {  // one chunk of lookahead: pend[] has a whole chunk-time to land
+#pragma unroll
+                for (int k = 0; k < PENDL; ++k) dstage[(size_t)(pend_q % NS) * CH + ll + 64 * k] = pend[k];
+                ++pend_q;
+#pragma unroll
+                for (int k = 0; k < PENDL; ++k) {
+                    const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
+                    pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
+                }
+            }
+            if ((lv & 63) == 0) {  // level bounds: LDS holds [lv, lv+128), lpend = [lv+128, lv+192)
+                lvb[(lv + 128 + ll) & (LVR - 1)] = lpend;
+                const int j = lv + 192 + ll;
+                lpend = lev_start[j < nlev ? j : nlev];
+            }
+            if (ll == 0) s_miss[(lv + 1) & 1] = 0;
+        } else {
+            // ---- read phase
+            d = box[m];
+            if (d.x >= 0 && d.z >= 0) {
+                const u64 pr = ring[(size_t)((d.w >> 10) & 1023) * H + (((d.w >> 26) & 63) & hm)];
+                if ((int)(unsigned)pr == d.z) other = (int)(pr >> 32);
+                else { miss = true; s_miss[lv & 1] = 1; }
+            }
+            for (int i = t_cur + m; i < t_nxt; i += npad) {  // mailbox of the next level
+                const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
+                nbox[dd.w & 1023] = dd;
+            }
+        }
+        lds_barrier();
+        if (s_miss[lv & 1]) {  // rare, workgroup-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (miss) other = __hip_atomic_load(&L[(size_t)d.z * npad + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- write phase
+        if (d.x >= 0) {
+            int v = mine > other ? mine : other;
+            if (col == m) v = d.x;
+            mine = v;
+            L[(size_t)d.x * npad + col] = v;
+            ring[(size_t)m * H + (((d.w >> 20) & 63) & hm)] = ((u64)(unsigned)v << 32) | (unsigned)d.x;
+            box[m].x = -1;  // consumed
+        }
+        lds_barrier();
+        t_cur = t_nxt; t_nxt = t_nn;
+    }
+}
+
+
+// Fifth version = the fourth with ONE barrier per level:
+//  * the loader wave also scatters the next level's descriptors into the member mailboxes;
+//  * workers read their ring entries and write their new entry in the same phase.  The only
+//    entry a reader could see being overwritten is the one exactly H events older than its
+//    creator's event of this level; readers never touch it: they compare the wanted chain
+//    position with the creator's newest position (a per-member LDS word, read racily with a
+//    margin of two) and take the memory path for anything H-2 or more positions old;
+//  * no workgroup-wide drain for that memory path: worker waves issue nothing but stores (at
+//    most one store instruction per level), so `s_waitcnt vmcnt(6)` once per level guarantees
+//    that every row stored seven or more levels ago has reached L2 — and a row that old is the
+//    only kind that can miss the ring (H >= 16).  Rows of earlier kernels are visible anyway.
+template <int PENDL>
+__global__ void __launch_bounds__(320)
+k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
+                  const int* __restrict__ prev_head, int* L, int npad, int H, int chs) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr int NS = 4;
+    constexpr int LVR = 256;
+    const int CH = 1 << chs;
+    int4* dstage = (int4*)smem;                                   // [NS][CH]
+    int4* mbox = dstage + (size_t)NS * CH;                        // [2][npad]
+    u64* ring = (u64*)(mbox + 2 * (size_t)npad);                  // [npad][H] {value << 32 | id}
+    int* lvb = (int*)(ring + (size_t)npad * H);                   // [LVR]
+    int* newest = lvb + LVR;                                      // [npad] newest chain position & 63
+    const int tid = threadIdx.x;
+    const int BT = blockDim.x;
+    const bool loader = tid >= npad;
+    const int m = tid;
+    const int ll = tid - npad;
+    const int nblk = gridDim.x;
+    const int col = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int hm = H - 1;
+    const int total = lev_start[nlev];
+    for (int i = tid; i < npad * H; i += BT) ring[i] = 0xffffffffffffffffull;
+    for (int i = tid; i < 2 * npad; i += BT) mbox[i] = make_int4(-1, -1, -1, 0);
+    for (int i = tid; i < npad; i += BT) newest[i] = 0;
+    for (int i = tid; i < 2 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
+    for (int i = tid; i < 128; i += BT) lvb[i] = lev_start[i < nlev ? i : nlev];
+    int pend_q = 2;
+    int4 pend[PENDL];
+    int lpend = 0;
+    int mine = -1;
+    int last_store = -1000;
+    if (loader) {
+#pragma unroll
+        for (int k = 0; k < PENDL; ++k) {
+            const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
+            pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
+        }
+        const int j = 128 + ll;
+        lpend = lev_start[j < nlev ? j : nlev];
+    } else {
+        const int ph = prev_head[m];
+        if (ph >= 0) mine = L[(size_t)ph * npad + col];
+    }
+    lds_barrier();
+    int t_cur = 0, t_nxt = 0;
+    if (loader) {
+        t_cur = lvb[1];
+        t_nxt = lvb[2];
+        for (int i = lvb[0] + ll; i < t_cur; i += 64) {  // mailbox of level 0
+            const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
+            mbox[dd.w & 1023] = dd;
+        }
+    }
+    lds_barrier();
+    for (int lv = 0; lv < nlev; ++lv) {
+        int4* box = mbox + (size_t)(lv & 1) * npad;
+        if (loader) {
+            int4* nbox = mbox + (size_t)((lv + 1) & 1) * npad;
+            const int t_nn = lvb[(lv + 3) & (LVR - 1)];
+            for (int i = t_cur + ll; i < t_nxt; i += 64) {  // mailbox of the next level
+                const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
+                nbox[dd.w & 1023] = dd;
+            }
+            const int need_q = t_nn > 0 ? (t_nn - 1) >> chs : 0;
+            while (need_q + 1 >= pend_q) {
+#pragma unroll
+                for (int k = 0; k < PENDL; ++k) dstage[(size_t)(pend_q % NS) * CH + ll + 64 * k] = pend[k];
+                ++pend_q;
+#pragma unroll
+                for (int k = 0; k < PENDL; ++k) {
+                    const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
+                    pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
+                }
+            }
+            if ((lv & 63) == 0) {
+                lvb[(lv + 128 + ll) & (LVR - 1)] = lpend;
+                const int j = lv + 192 + ll;
+                lpend = lev_start[j < nlev ? j : nlev];
+            }
+            t_cur = t_nxt;
+            t_nxt = t_nn;
+        } else {
+            const int4 d = box[m];
+            if (d.x >= 0) {
+                int other = -1;
+                if (d.z >= 0) {
+                    const int co = (d.w >> 10) & 1023;
+                    const int so6 = (d.w >> 26) & 63;
+                    const u64 pr = ring[(size_t)co * H + (so6 & hm)];
+                    const int age = (newest[co] - so6) & 63;
+                    if (age < H - 2 && (int)(unsigned)pr == d.z) other = (int)(pr >> 32);
+                    else other = __hip_atomic_load(&L[(size_t)d.z * npad + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                int v = mine > other ? mine : other;
+                if (col == m) v = d.x;
+                mine = v;
+                const int se6 = (d.w >> 20) & 63;
+                L[(size_t)d.x * npad + col] = v;
+                ring[(size_t)m * H + (se6 & hm)] = ((u64)(unsigned)v << 32) | (unsigned)d.x;
+                newest[m] = se6;
+                box[m].x = -1;
+            }
+            // store-completion bound: at most 6 store instructions of this wave in flight, and
+            // a lone store is drained explicitly six levels after it was issued
+            if (__ballot(d.x >= 0)) last_store = lv;
+            if (lv - last_store == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        lds_barrier();
     }
 }
 
@@ -349,9 +612,9 @@ __global__ void __launch_bounds__(1024)
 k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
           const int* __restrict__ chain_start, const int* __restrict__ chain_ev,
           int* lo, int* lopos, int* evalround, int* evalpos,
-          int* lo_r, int* cur, int* unres, int* lo_next, int* pos_next,
-          int* cand, const unsigned char* __restrict__ res) {
+          int* lo_r, int* cur, int* unres, int* lo_next, int* pos_next, int* found) {
     __shared__ int s_min;
+    __shared__ int s_max;
     __shared__ int s_cnt;
     const int c = threadIdx.x;
     if (st->done) return;
@@ -362,21 +625,19 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
     const int clen = chain_start[c + 1] - cs;
     int un = unres[c];
     int curc = cur[c];
+    const int fnd = found[c];  // smallest candidate slot whose tally passed (INF: none)
     const int lo_r1 = (r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
     const int lo_r2 = (r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
     const int lopos_r1 = (r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
     int evr_now = evalround[c], evp_now = evalpos[c];
+    int my_lo_next = (iter > 0) ? lo_next[c] : SW_INF;
+    int my_pos_next = (iter > 0) ? pos_next[c] : 0;
     int mlo = st->mlo, mhi = st->mhi;
-    int found = -1;
+    found[c] = SW_INF;
     if (iter > 0 && un) {
-        for (int j = K - 1; j >= 0; --j)
-            if (res[c * K + j]) found = j;
-    }
-    int my_lo_next = SW_INF, my_pos_next = 0;
-    if (iter > 0 && un) {
-        if (found >= 0) {
-            my_lo_next = cand[c * K + found];
-            my_pos_next = curc + found;
+        if (fnd != SW_INF) {
+            my_pos_next = curc + fnd;
+            my_lo_next = chain_ev[cs + my_pos_next];
             lo_next[c] = my_lo_next;
             pos_next[c] = my_pos_next;
             un = 0;
@@ -389,9 +650,6 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
         } else {
             curc += K;
         }
-    } else if (iter > 0) {
-        my_lo_next = lo_next[c];
-        my_pos_next = pos_next[c];
     }
     int nun = __syncthreads_count(un);
     int need_mask = 0, done = 0, err = 0, max_round = 0;
@@ -443,26 +701,21 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
             nx = (r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
         }
     }
+    if (done) un = 0;
     unres[c] = un;
     cur[c] = curc;
-    int live = 0, maxc = -1;
-    for (int j = 0; j < K; ++j) {
-        const int p = curc + j;
-        const int ok = un && !done && p < clen;
-        const int ev = ok ? chain_ev[cs + p] : -1;
-        cand[c * K + j] = ev;
-        live += ok;
-        maxc = ev > maxc ? ev : maxc;
-    }
-    if (c == 0) { s_cnt = 0; s_min = -1; }
+    // candidates of member c in the next tally launch: chain positions [curc, curc + K)
+    const int live = un ? (clen - curc < K ? clen - curc : K) : 0;
+    const int maxc = live ? chain_ev[cs + curc + live - 1] : -1;
+    if (c == 0) { s_cnt = 0; s_max = -1; }
     __syncthreads();
-    if (live) { atomicAdd(&s_cnt, live); atomicMax(&s_min, maxc); }
+    if (live) { atomicAdd(&s_cnt, live); atomicMax(&s_max, maxc); }
     __syncthreads();
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
     // (hops beyond the cap are rebuilt from their rows by the tally kernel)
     int mask_from = mlo;
     {
-        int want = s_min + 1;
+        int want = s_max + 1;
         if (want - mlo > MCAP) want = mlo + MCAP;
         if (want > N) want = N;
         if (need_mask) {
@@ -538,20 +791,22 @@ __device__ __forceinline__ void tally_chunk(const u64 vm, const int j, const uin
 // Round loop, step 3: evaluate SS_r(e) for the candidate list.
 template <int NW, bool UNIT>
 __global__ void __launch_bounds__(256)
-k_tally_candidates(RState* st, const int* __restrict__ cand, const int* __restrict__ L,
-                   const int* __restrict__ cr, const int* __restrict__ sp,
+k_tally_candidates(RState* st, int K, const int* __restrict__ unres, const int* __restrict__ cur,
+                   const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int* found,
+                   const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
                    const int* __restrict__ lo_r, const u64* __restrict__ Mb,
-                   const uint32_t* __restrict__ stake, uint32_t tot2, unsigned char* res, int npad) {
+                   const uint32_t* __restrict__ stake, uint32_t tot2, int npad) {
     __shared__ u64 s_hm[4][NW * 64];
     if (st->done) return;
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
     const int w = blockIdx.x * 4 + wib;
-    const int e = cand[w];
-    if (e < 0) {
-        if (lane == 0) res[w] = 0;
-        return;
-    }
+    const int cm = w / K, cj = w - cm * K;  // member, candidate slot
+    if (!unres[cm]) return;
+    const int ccs = chain_start[cm];
+    const int cp = cur[cm] + cj;
+    if (cp >= chain_start[cm + 1] - ccs) return;
+    const int e = chain_ev[ccs + cp];
     const int mlo = st->mlo, mhi = st->mhi;
     u64* hm = s_hm[wib];
     const int ce = cr[e], spe = sp[e];
@@ -600,7 +855,7 @@ k_tally_candidates(RState* st, const int* __restrict__ cand, const int* __restri
 #pragma unroll
     for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(3u * hits[j] > tot2));
     if (lane == 0) {
-        res[w] = (3u * cnt > tot2) ? 1 : 0;  // count of members vs the STAKE threshold (Q2)
+        if (3u * cnt > tot2) atomicMin(&found[cm], cj);  // count of members vs the STAKE threshold (Q2)
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
 }
@@ -653,9 +908,10 @@ constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 
 template <int NW>
 __global__ void __launch_bounds__(256)
-k_tally_bits(RState* st, const int* __restrict__ cand, const int* __restrict__ L,
-             const int* __restrict__ cr, const int* __restrict__ sp, const int* __restrict__ lo_r,
-             const uint32_t* __restrict__ Mb32, uint32_t tot2, unsigned char* res, int npad) {
+k_tally_bits(RState* st, int K, const int* __restrict__ unres, const int* __restrict__ cur,
+             const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int* found,
+             const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
+             const int* __restrict__ lo_r, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
     constexpr int G = 64 / W32;          // hop groups
     constexpr int HPL = (64 * NW) / G;   // hops per lane
@@ -665,11 +921,12 @@ k_tally_bits(RState* st, const int* __restrict__ cand, const int* __restrict__ L
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
     const int wv = blockIdx.x * 4 + wib;
-    const int e = cand[wv];
-    if (e < 0) {
-        if (lane == 0) res[wv] = 0;
-        return;
-    }
+    const int cm = wv / K, cj = wv - cm * K;  // member, candidate slot
+    if (!unres[cm]) return;
+    const int ccs = chain_start[cm];
+    const int cp = cur[cm] + cj;
+    if (cp >= chain_start[cm + 1] - ccs) return;
+    const int e = chain_ev[ccs + cp];
     const int mlo = st->mlo, mhi = st->mhi;
     int* pk = s_pk[wib];
     const int ce = cr[e], spe = sp[e];
@@ -759,7 +1016,7 @@ k_tally_bits(RState* st, const int* __restrict__ cand, const int* __restrict__ L
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
     if (lane == 0) {
-        res[wv] = (3u * cnt > tot2) ? 1 : 0;  // count of members vs the STAKE threshold (Q2)
+        if (3u * cnt > tot2) atomicMin(&found[cm], cj);  // count of members vs the STAKE threshold (Q2)
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
 }

@@ -39,7 +39,10 @@ struct sw_ctx {
     // host mirror of the DAG (validation, height, chains)
     std::vector<int32_t> cr, sp, op, ht;
     std::vector<int32_t> head;      // latest event per member (-1 none)
+    std::vector<int32_t> first_ev;  // first event (root) per member (-1 none)
     std::vector<int32_t> nev;       // events per member so far (next chain position)
+    struct AppendRec { int64_t first, K; int hmin, hmax; };
+    std::vector<AppendRec> appends;  // per sw_append_events call: range and height span (ingest-time metadata)
     bool has_forks = false;
     int max_height = 0;
     int64_t N = 0, cap = 0, divided = 0;
@@ -51,6 +54,8 @@ struct sw_ctx {
     DBuf<double> d_t;
     DBuf<u64> d_S;
     DBuf<int32_t> d_chain_start;  // npad + 1
+    DBuf<int32_t> d_prev_head;    // npad: latest divided event per member (-1 none)
+    std::vector<int32_t> divided_head;
     DBuf<uint32_t> d_stake;       // npad
 
     // device: levels
@@ -65,8 +70,7 @@ struct sw_ctx {
     DBuf<unsigned char> d_cons, d_newc;
     DBuf<u64> d_Sw;
     int Sw_rows = 0;
-    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_cand;
-    DBuf<unsigned char> d_res;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found;
     DBuf<u64> d_Mb;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;
@@ -79,10 +83,17 @@ struct sw_ctx {
     int K = 32;        // candidates per member per tally launch
     int MCAP = 0;      // band size (events)
     int BATCH = 24;    // loop iterations between host checks
-    int cansee_impl = 2;  // 0 = global-memory levels, 1 = LDS ring, 2 = LDS ring + streamed descriptors
+    int cansee_impl = 5;  // 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
+
+    // round-loop graph
+    struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; int K, tally_impl, BATCH, MCAP; };
+    bool use_graph = true;
+    hipGraph_t loop_graph = nullptr;
+    hipGraphExec_t loop_exec = nullptr;
+    GraphKey loop_key{};
 
     // profiling
     bool profiling = false;
@@ -260,11 +271,12 @@ int rebuild_chains(sw_ctx* c) {
 }
 
 // geometry of the streaming can_see kernel for this member count
-struct CanseeCfg { int CB, MAXP, H, chs; size_t lds; };
-CanseeCfg cansee_cfg(int npad, int want_H) {
+struct CanseeCfg { int CB, MAXP, BT, H, chs; size_t lds; };
+CanseeCfg cansee_cfg(int npad, int want_H, int impl) {
     CanseeCfg g{};
-    g.CB = npad <= 256 ? 16 : 4;
-    const int EPB = 1024 / g.CB;
+    if (npad <= 256 && impl == 3) { g.CB = 4; g.BT = 256; }      // 4 waves, 4 columns: npad/4 workgroups
+    else { g.CB = npad <= 256 ? 16 : 4; g.BT = 1024; }
+    const int EPB = g.BT / g.CB;
     g.MAXP = std::max(1, npad / EPB);
     int ch = 256;
     g.chs = 8;
@@ -278,15 +290,15 @@ CanseeCfg cansee_cfg(int npad, int want_H) {
     return g;
 }
 
-template <int CB, int MAXP>
+template <int CB, int MAXP, int BT>
 int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_cansee_stream<CB, MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_cansee_stream<CB, MAXP, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_cansee_stream<CB, MAXP>), dim3(c->npad / CB), dim3(1024), g.lds, c->stream,
+    hipLaunchKernelGGL((k_cansee_stream<CB, MAXP, BT>), dim3(c->npad / CB), dim3(BT), g.lds, c->stream,
                        (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, g.H, g.chs);
     return SW_OK;
 }
@@ -294,13 +306,44 @@ int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
 template <int NW>
 int launch_cansee(sw_ctx* c, int nlev) {
     constexpr int CB = 16;
-    if (c->cansee_impl == 2) {
-        const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req);
-        if (g.CB == 16 && g.MAXP == 1) CHK((launch_cansee_stream<16, 1>(c, nlev, g)));
-        else if (g.CB == 16 && g.MAXP == 2) CHK((launch_cansee_stream<16, 2>(c, nlev, g)));
-        else if (g.CB == 16) CHK((launch_cansee_stream<16, 4>(c, nlev, g)));
-        else if (g.MAXP == 2) CHK((launch_cansee_stream<4, 2>(c, nlev, g)));
-        else CHK((launch_cansee_stream<4, 4>(c, nlev, g)));
+    if ((c->cansee_impl == 4 || c->cansee_impl == 5) && c->npad <= 256) {
+        // member-per-thread kernel: npad workgroups of npad workers + one loader wave
+        const int chs = 10, CH = 1 << chs;
+        int H = 16;
+        if (c->cansee_impl == 5 && c->ring_H_req > 0 && c->ring_H_req < 16) c->ring_H_req = 16;
+        if (c->ring_H_req >= 1 && c->ring_H_req <= 64 && (c->ring_H_req & (c->ring_H_req - 1)) == 0) H = c->ring_H_req;
+        const size_t lds = (size_t)4 * CH * 16 + (size_t)2 * c->npad * 16 + (size_t)c->npad * H * 8 + 256 * 4 + 16;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_cansee_member<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                (void)hipGetLastError();
+            attr_set = true;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), c->npad * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        if (c->cansee_impl == 5) {
+            static bool attr_set5 = false;
+            if (!attr_set5) {
+                if (hipFuncSetAttribute((const void*)k_cansee_member1b<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    (void)hipGetLastError();
+                attr_set5 = true;
+            }
+            hipLaunchKernelGGL(k_cansee_member1b<16>, dim3(c->npad), dim3(c->npad + 64), lds + (size_t)c->npad * 4, c->stream,
+                               (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, (const int*)c->d_prev_head.p,
+                               c->d_L.p, c->npad, std::max(H, 16), chs);
+        } else
+        hipLaunchKernelGGL(k_cansee_member<16>, dim3(c->npad), dim3(c->npad + 64), lds, c->stream,
+                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, (const int*)c->d_prev_head.p,
+                           c->d_L.p, c->npad, H, chs);
+    } else if (c->cansee_impl >= 2) {
+        const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req, c->cansee_impl);
+        if (g.BT == 256 && g.MAXP == 1) CHK((launch_cansee_stream<4, 1, 256>(c, nlev, g)));
+        else if (g.BT == 256 && g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 256>(c, nlev, g)));
+        else if (g.BT == 256) CHK((launch_cansee_stream<4, 4, 256>(c, nlev, g)));
+        else if (g.CB == 16 && g.MAXP == 1) CHK((launch_cansee_stream<16, 1, 1024>(c, nlev, g)));
+        else if (g.CB == 16 && g.MAXP == 2) CHK((launch_cansee_stream<16, 2, 1024>(c, nlev, g)));
+        else if (g.CB == 16) CHK((launch_cansee_stream<16, 4, 1024>(c, nlev, g)));
+        else if (g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 1024>(c, nlev, g)));
+        else CHK((launch_cansee_stream<4, 4, 1024>(c, nlev, g)));
     } else if (c->cansee_impl == 1 && c->ring_H >= 1) {
         const size_t lds = ((size_t)c->npad * c->ring_H * CB + (size_t)c->npad * c->ring_H) * sizeof(int);
         hipLaunchKernelGGL(k_cansee_ring<CB>, dim3(c->npad / CB), dim3(1024), lds, c->stream,
@@ -314,6 +357,77 @@ int launch_cansee(sw_ctx* c, int nlev) {
     return SW_OK;
 }
 
+// one iteration of the round loop = resolve -> band masks -> tally (all self-guarding on
+// the device-side state, so extra iterations after `done` are no-ops)
+template <int NW>
+void enqueue_iteration(sw_ctx* c, std::vector<Span>* tally_spans) {
+    const int np = c->npad, K = c->K;
+    const int tally_blocks = np * K / 4;
+    const int mask_blocks = std::min(std::max(c->MCAP / 4, 1), 2048);
+    const uint32_t tot2 = 2u * c->tot;
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(np), 0, c->stream, c->d_state, np, K, (int)c->N,
+                       c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
+                       c->d_lo.p, c->d_lopos.p, c->d_evalround.p, c->d_evalpos.p, c->d_lo_r.p,
+                       c->d_cur.p, c->d_unres.p, c->d_lo_next.p, c->d_pos_next.p, c->d_found.p);
+    hipLaunchKernelGGL(k_band_masks<NW>, dim3(mask_blocks), dim3(256), 0, c->stream,
+                       (const RState*)c->d_state, (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                       (const int*)c->d_lo_r.p, c->d_Mb.p, np);
+    Span s{};
+    if (tally_spans) s = span_begin(c);
+    if (c->unit_stake && c->tally_impl == 1)
+        hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream,
+                           c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, c->d_found.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                           (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const uint32_t*)c->d_Mb.p,
+                           tot2, np);
+    else if (c->unit_stake)
+        hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream,
+                           c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, c->d_found.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                           (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
+                           (const uint32_t*)c->d_stake.p, tot2, np);
+    else
+        hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream,
+                           c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, c->d_found.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p,
+                           (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
+                           (const uint32_t*)c->d_stake.p, tot2, np);
+    if (tally_spans) { span_end(c, s); tally_spans->push_back(s); }
+    c->ctr.kernel_launches += 3;
+}
+
+// the loop body as a replayable hipGraph (BATCH iterations = 3*BATCH kernel nodes); the
+// kernel arguments are frozen at capture, so the graph is rebuilt when any of them changes
+template <int NW>
+int launch_batch(sw_ctx* c, std::vector<Span>* tally_spans) {
+    if (!c->use_graph || tally_spans) {
+        for (int it = 0; it < c->BATCH; ++it) enqueue_iteration<NW>(c, tally_spans);
+        return SW_OK;
+    }
+    sw_ctx::GraphKey key;
+    memset(&key, 0, sizeof key);
+    key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
+    key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
+    key.BATCH = c->BATCH; key.MCAP = c->MCAP;
+    if (!c->loop_exec || memcmp(&key, &c->loop_key, sizeof key) != 0) {
+        if (c->loop_exec) { (void)hipGraphExecDestroy(c->loop_exec); c->loop_exec = nullptr; }
+        if (c->loop_graph) { (void)hipGraphDestroy(c->loop_graph); c->loop_graph = nullptr; }
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int64_t launches_before = c->ctr.kernel_launches;
+        for (int it = 0; it < c->BATCH; ++it) enqueue_iteration<NW>(c, nullptr);
+        c->ctr.kernel_launches = launches_before;
+        HIPCHK(c, hipStreamEndCapture(c->stream, &c->loop_graph));
+        HIPCHK(c, hipGraphInstantiate(&c->loop_exec, c->loop_graph, nullptr, nullptr, 0));
+        c->loop_key = key;
+    }
+    HIPCHK(c, hipGraphLaunch(c->loop_exec, c->stream));
+    c->ctr.kernel_launches += 3 * c->BATCH;
+    return SW_OK;
+}
+
 template <int NW>
 int run_round_loop(sw_ctx* c, int r_start, float* tally_ms_out, int* tally_launches_out) {
     const int np = c->npad, K = c->K;
@@ -321,43 +435,13 @@ int run_round_loop(sw_ctx* c, int r_start, float* tally_ms_out, int* tally_launc
     init.r = r_start;
     HIPCHK(c, hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_unres.p, 0, np * sizeof(int32_t), c->stream));
-    const int tally_blocks = np * K / 4;
-    const int mask_blocks = std::min(std::max(c->MCAP / 4, 1), 2048);
-    const uint32_t tot2 = 2u * c->tot;
+    CHK(fill_i32(c, c->d_found.p, np, SW_INF));
     std::vector<Span> tally_spans;
     RState st{};
     int launched = 0;
     for (;;) {
         CHK(ensure_rounds(c, c->R + launched + c->BATCH + 4));
-        for (int it = 0; it < c->BATCH; ++it) {
-            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(np), 0, c->stream, c->d_state, np, K, (int)c->N,
-                               c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
-                               c->d_lo.p, c->d_lopos.p, c->d_evalround.p, c->d_evalpos.p, c->d_lo_r.p,
-                               c->d_cur.p, c->d_unres.p, c->d_lo_next.p, c->d_pos_next.p, c->d_cand.p,
-                               (const unsigned char*)c->d_res.p);
-            hipLaunchKernelGGL(k_band_masks<NW>, dim3(mask_blocks), dim3(256), 0, c->stream,
-                               (const RState*)c->d_state, (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                               (const int*)c->d_lo_r.p, c->d_Mb.p, np);
-            Span s = span_begin(c);
-            if (c->unit_stake && c->tally_impl == 1)
-                hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream,
-                                   c->d_state, (const int*)c->d_cand.p, (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                                   (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const uint32_t*)c->d_Mb.p,
-                                   tot2, c->d_res.p, np);
-            else if (c->unit_stake)
-                hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream,
-                                   c->d_state, (const int*)c->d_cand.p, (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                                   (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
-                                   (const uint32_t*)c->d_stake.p, tot2, c->d_res.p, np);
-            else
-                hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream,
-                                   c->d_state, (const int*)c->d_cand.p, (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                                   (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
-                                   (const uint32_t*)c->d_stake.p, tot2, c->d_res.p, np);
-            span_end(c, s);
-            if (c->profiling) tally_spans.push_back(s);
-            c->ctr.kernel_launches += 3;
-        }
+        CHK(launch_batch<NW>(c, c->profiling ? &tally_spans : nullptr));
         launched += c->BATCH;
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
@@ -390,9 +474,19 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     Span sp_total = span_begin(c);
     // ---- level buckets + can_see rows ----
     int hmin = 0x7fffffff, hmax = -1;
-    for (int64_t e = first; e < first + K; ++e) {
-        hmin = std::min(hmin, c->ht[e]);
-        hmax = std::max(hmax, c->ht[e]);
+    {
+        // height span of the batch: from the ingest-time records when the batch is a union of
+        // whole appends (the normal case), else by scanning
+        int64_t covered = first;
+        for (const auto& a : c->appends) {
+            if (a.first == covered && a.first + a.K <= first + K) {
+                hmin = std::min(hmin, a.hmin); hmax = std::max(hmax, a.hmax); covered += a.K;
+            }
+        }
+        if (covered != first + K) {
+            hmin = 0x7fffffff; hmax = -1;
+            for (int64_t e = first; e < first + K; ++e) { hmin = std::min(hmin, c->ht[e]); hmax = std::max(hmax, c->ht[e]); }
+        }
     }
     const int nlev = hmax - hmin + 1;
     CHK(dgrow(c, c->d_lev_cnt, nlev, 0));
@@ -420,18 +514,21 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         // members touched by this batch; a member's first event (its root) opens its chain
         // at round 0: lo[0][m] = root, chain position 0 (swirld.py:195-198)
         bool row0_dirty = false;
-        for (int64_t e = first; e < first + K; ++e) {
-            const int m = c->cr[e];
-            if (c->front[m] < 0) {
-                c->lo0_h[m] = (int32_t)e;
+        std::vector<char> touched(c->n, 0);
+        if (first + K == c->N) {  // dividing through the newest event: per-member heads tell everything
+            for (int m = 0; m < c->n; ++m)
+                if (c->head[m] >= first) touched[m] = 1;
+        } else {
+            for (int64_t e = first; e < first + K; ++e) touched[c->cr[e]] = 1;
+        }
+        for (int m = 0; m < c->n; ++m) {
+            if (touched[m] && c->front[m] < 0) {  // the member's root is in this batch
+                c->lo0_h[m] = c->first_ev[m];
                 c->front[m] = 0;
                 row0_dirty = true;
             }
-        }
-        std::vector<char> touched(c->n, 0);
-        for (int64_t e = first; e < first + K; ++e) touched[c->cr[e]] = 1;
-        for (int m = 0; m < c->n; ++m)
             if (touched[m]) r_start = std::min(r_start, c->front[m]);
+        }
         if (r_start == 0x7fffffff) r_start = 0;
         if (row0_dirty)
             HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -470,7 +567,14 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     }
     HIPCHK(c, hipGetLastError());
     c->sw_dirty_from = std::min(c->sw_dirty_from, std::max(r_start, 1));
+    if (first + K == c->N) std::copy(c->head.begin(), c->head.end(), c->divided_head.begin());
+    else for (int64_t e = first; e < first + K; ++e) c->divided_head[c->cr[e]] = (int32_t)e;
     c->divided = first + K;
+    {
+        size_t keep = 0;
+        while (keep < c->appends.size() && c->appends[keep].first + c->appends[keep].K <= c->divided) ++keep;
+        c->appends.erase(c->appends.begin(), c->appends.begin() + keep);
+    }
     c->ctr.events_divided += K;
     c->ctr.rounds = R;
     if (c->profiling) {
@@ -725,13 +829,16 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->stake_h.assign(c->npad, 0);
     for (int i = 0; i < n_members; ++i) c->stake_h[i] = (uint32_t)stake[i];
     c->head.assign(n_members, -1);
+    c->first_ev.assign(n_members, -1);
     c->front.assign(n_members, -1);
+    c->divided_head.assign(c->npad, -1);
     c->ord_pos.assign(n_members, 0);
     c->lo0_h.assign(c->npad, SW_INF);
     c->MCAP = std::max(128 * c->npad, 8192);
     if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, atoi(s));
     if (const char* s = getenv("SW_BAND")) c->MCAP = std::max(64, atoi(s));
     if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
+    if (const char* s = getenv("SW_GRAPH")) c->use_graph = atoi(s) != 0;
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
     c->nev.assign(n_members, 0);
@@ -763,8 +870,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_unres, np, 0));
     CCHK(dgrow(c, c->d_lo_next, np, 0));
     CCHK(dgrow(c, c->d_pos_next, np, 0));
-    CCHK(dgrow(c, c->d_cand, (size_t)np * c->K, 0));
-    CCHK(dgrow(c, c->d_res, (size_t)np * c->K, 0));
+    CCHK(dgrow(c, c->d_found, np, 0));
+    CCHK(dgrow(c, c->d_prev_head, np, 0));
     CCHK(dgrow(c, c->d_Mb, (size_t)c->MCAP * c->nw, 0));
     CCHK(fill_i32(c, c->d_evalround.p, np, -1));
     CCHK(fill_i32(c, c->d_evalpos.p, np, 0));
@@ -772,7 +879,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(fill_i32(c, c->d_cur.p, np, 0));
     CCHK(fill_i32(c, c->d_lo_next.p, np, SW_INF));
     CCHK(fill_i32(c, c->d_pos_next.p, np, 0));
-    CHIP(hipMemsetAsync(c->d_res.p, 0, (size_t)np * c->K, c->stream));
     CCHK(ensure_rounds(c, 256));
     if (c->ring_H >= 1) {
         const size_t lds = ((size_t)np * c->ring_H * 16 + (size_t)np * c->ring_H) * sizeof(int);
@@ -796,15 +902,17 @@ int sw_destroy(sw_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
-    dfree(c->d_chain_start); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_chain_start); dfree(c->d_prev_head); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
-    dfree(c->d_pos_next); dfree(c->d_cand); dfree(c->d_res); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_Mb);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
+    if (c->loop_exec) (void)hipGraphExecDestroy(c->loop_exec);
+    if (c->loop_graph) (void)hipGraphDestroy(c->loop_graph);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -852,6 +960,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         c->ht[e] = s < 0 ? 0 : std::max(c->ht[s], c->ht[o]) + 1;  // swirld.py:117-120
         c->max_height = std::max(c->max_height, c->ht[e]);
         if (c->head[m] != s) c->has_forks = true;  // second child of s, or a second root
+        if (c->first_ev[m] < 0) c->first_ev[m] = (int32_t)e;
         c->head[m] = (int32_t)e;
         seq[i] = c->nev[m]++;  // position on the member's self-parent chain
         coin[i] = sig64 ? (unsigned char)(sig64[64 * i] >> 7) : 0;  // swirld.py:272
@@ -859,6 +968,11 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     c->sig_h.resize((size_t)(N0 + K) * 64);
     if (sig64) memcpy(c->sig_h.data() + (size_t)N0 * 64, sig64, (size_t)K * 64);
     else memset(c->sig_h.data() + (size_t)N0 * 64, 0, (size_t)K * 64);
+    {
+        int hmin = 0x7fffffff, hmax = -1;
+        for (int64_t e = N0; e < N0 + K; ++e) { hmin = std::min(hmin, c->ht[e]); hmax = std::max(hmax, c->ht[e]); }
+        c->appends.push_back({N0, K, hmin, hmax});
+    }
     c->N = N0 + K;
     c->chains_dirty = true;
     const size_t b4 = (size_t)K * sizeof(int32_t);
@@ -874,6 +988,10 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     else HIPCHK(c, hipMemsetAsync(c->d_sig.p + (size_t)N0 * 64, 0, (size_t)K * 64, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_round.p + N0, 0xff, b4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // caller buffers may be released on return
+    // per-member chain index (CSR): part of the ingest-time layout of the hashgraph store.  Built
+    // here for bulk appends; for trickles of small appends it is rebuilt lazily by the next
+    // divide_rounds call instead (one O(N) pass either way).
+    if (K >= 4096 || K * 8 >= c->N) CHK(rebuild_chains(c));
     return SW_OK;
 }
 
@@ -923,6 +1041,7 @@ int sw_rewind(sw_ctx* c) {
     if (c->N) HIPCHK(c, hipMemsetAsync(c->d_round.p, 0xff, (size_t)c->N * sizeof(int32_t), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::fill(c->front.begin(), c->front.end(), -1);
+    std::fill(c->divided_head.begin(), c->divided_head.end(), -1);
     std::fill(c->lo0_h.begin(), c->lo0_h.end(), SW_INF);
     std::fill(c->cons_h.begin(), c->cons_h.end(), 0);
     c->divided = 0;

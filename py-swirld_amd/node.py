@@ -131,6 +131,21 @@ class _FamousView(Mapping):
         return len(self._dict())
 
 
+class _VotesView(Mapping):
+    """Node.votes (swirld.py:60-61) is a diagnostic by-product of decide_fame in the reference
+    (nothing outside decide_fame reads it).  The GPU elections keep votes as per-round member
+    bitmasks and do not materialise the {voter -> {candidate -> bool}} dict."""
+
+    def __getitem__(self, h):
+        raise NotImplementedError("Node.votes is not materialised by the GPU elections")
+
+    def __iter__(self):
+        return iter(())
+
+    def __len__(self):
+        return 0
+
+
 class Node:
     def __init__(self, kp, network, n_nodes, stake, device=0):
         self.pk, self.sk = kp
@@ -167,6 +182,7 @@ class Node:
         self.can_see = _CanSeeView(self)
         self.witnesses = _WitnessView(self)
         self.famous = _FamousView(self)
+        self.votes = _VotesView()
 
         # the node's own root event (swirld.py:75-80)
         h, ev = self.new_event(None, ())

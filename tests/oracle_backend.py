@@ -1,0 +1,50 @@
+"""Test scaffolding: an object with the `Hashgraph` (py-swirld_amd/engine.py) interface that
+is backed by the CPU oracle, so that the HOST logic of the drop-in Node (hash <-> index
+maps, lazy views, gossip, call protocol) can be exercised on a machine without a GPU by
+monkeypatching `node.Hashgraph` inside a test.  Never imported by the product."""
+import numpy as np
+
+from oracle.oracle import Oracle
+
+
+class OracleHashgraph:
+    def __init__(self, n_members, stake=None, coin_period=6, device=0):
+        self.n = n_members
+        self._o = Oracle(n_members, None if stake is None else np.asarray(stake, np.uint64), coin_period)
+
+    def append_events(self, creator, self_parent, other_parent, t=None, sig=None):
+        self._o.append_events(creator, self_parent, other_parent, t, sig)
+
+    @property
+    def num_events(self):
+        return self._o.N
+
+    def divide_rounds(self, first, K):
+        self._o.divide_rounds(first, K)
+
+    def decide_fame(self):
+        return self._o.decide_fame()
+
+    def find_order(self, rounds):
+        return self._o.find_order(rounds)
+
+    @property
+    def max_round(self):
+        return self._o.max_round
+
+    def rounds(self, first=0, K=None):
+        r = self._o.round
+        return r[first:] if K is None else r[first:first + K]
+
+    def can_see(self, first=0, K=None):
+        c = self._o.can_see
+        return c[first:] if K is None else c[first:first + K]
+
+    def witnesses(self, r0=0, r1=None):
+        return self._o.witnesses(r0, r1)
+
+    def famous(self, r0=0, r1=None):
+        return self._o.famous_table(r0, r1)
+
+    def close(self):
+        pass

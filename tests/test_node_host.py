@@ -1,0 +1,67 @@
+"""CPU: the HOST logic of the drop-in Node (py-swirld_amd/node.py) — hash <-> index maps,
+lazy dict views, gossip (sync / ask_sync), the main() call protocol — with the device
+backend swapped for the CPU oracle by monkeypatching `node.Hashgraph` (tests/
+oracle_backend.py).  The GPU path itself is covered by tests/test_gpu_node.py."""
+import contextlib
+import io
+
+import numpy as np
+
+import oracle_backend
+
+
+def test_node_main_loop_on_oracle_backend(pkg, monkeypatch):
+    monkeypatch.setattr(pkg.node, "Hashgraph", oracle_backend.OracleHashgraph)
+    with contextlib.redirect_stdout(io.StringIO()):
+        nodes = pkg.test(4, 250)
+    assert len(nodes) == 4
+    for nd in nodes:
+        N = len(nd._ids)
+        assert N == len(nd.hg) == len(nd.round) and N > 200
+        rounds = [nd.round[h] for h in nd._ids]
+        assert rounds[0] == 0 and max(rounds) == max(nd.witnesses)
+        # witnesses: first event of its creator in that round, registration order ascending
+        for r in nd.witnesses:
+            idx = [nd._index[h] for h in nd.witnesses[r].values()]
+            assert idx == sorted(idx)
+            for pk, h in nd.witnesses[r].items():
+                assert nd.hg[h].c == pk and nd.round[h] == r
+        # can_see[head]: own entry is the event itself, entries are by the right creators
+        row = nd.can_see[nd.head]
+        assert row[nd.pk] == nd.head
+        assert all(nd.hg[h].c == pk for pk, h in row.items())
+        # famous only for decided witnesses; consensus rounds are fully decided
+        for r in nd.consensus:
+            assert all(h in nd.famous for h in nd.witnesses[r].values())
+        # total order bookkeeping
+        assert len(set(nd.transactions)) == len(nd.transactions)
+        assert all(nd.idx[h] == i for i, h in enumerate(nd.transactions))
+        assert nd.tbd == set(nd.hg) - set(nd.transactions)
+        assert len(nd.transactions) > 50
+        # unknown ids raise KeyError like the reference's dicts
+        for view in (nd.round, nd.can_see):
+            try:
+                view[b"\\0" * 32]
+                raise AssertionError("KeyError expected")
+            except KeyError:
+                pass
+
+
+def test_divide_rounds_rejects_out_of_order(pkg, monkeypatch):
+    import pytest
+    monkeypatch.setattr(pkg.node, "Hashgraph", oracle_backend.OracleHashgraph)
+    kp = pkg.node.crypto.sign_keypair()
+    kp2 = pkg.node.crypto.sign_keypair()
+    stake = {kp[0]: 1, kp2[0]: 1}
+    a = pkg.Node(kp, {}, 2, stake)
+    b = pkg.Node(kp2, {}, 2, stake)
+    hb = b.head
+    a.add_event(hb, b.hg[hb])
+    h2, ev2 = a.new_event(None, (a.head, hb))
+    a.add_event(h2, ev2)
+    with pytest.raises(ValueError):
+        a.divide_rounds((h2, hb))          # not the order they were added in
+    with pytest.raises(KeyError):
+        a.divide_rounds((b"x" * 32,))
+    a.divide_rounds((hb, h2))
+    assert a.round[h2] == 0 and a.witnesses[0][kp2[0]] == hb
