@@ -24,6 +24,7 @@ struct RState {
     int need_mask;  // the band mask table must be (re)built for round r
     int mlo, mhi;   // band of event indices covered by the mask table
     int mask_from;  // first band event whose mask must be (re)built in this iteration
+    int N;          // events visible to this round-loop run (rows below N are complete)
     int iter;       // iterations executed in this call
     int n_unres;    // members still searching their first round-(r+1) event
     int max_round;  // valid when done
@@ -367,7 +368,7 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
 template <int PENDL>
 __global__ void __launch_bounds__(320)
 k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-                const int* __restrict__ prev_head, int* L, int npad, int H, int chs) {
+                const int* __restrict__ prev_head, int* prev_head_out, int* L, int npad, int H, int chs) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int NS = 4;     // descriptor chunks resident
     constexpr int LVR = 256;  // level-bound ring entries
@@ -396,6 +397,7 @@ k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start
     int4 pend[PENDL];
     int lpend = 0;        // loader: level bounds [lv+128, lv+192) in flight
     int mine = -1;        // worker: row value of the member's latest event
+    int last_e = -1;      // worker: the member's latest event (handed to the next batch)
     if (loader) {
 #pragma unroll
         for (int k = 0; k < PENDL; ++k) {
@@ -406,6 +408,7 @@ k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start
         lpend = lev_start[j < nlev ? j : nlev];
     } else {
         const int ph = prev_head[m];
+        last_e = ph;
         if (ph >= 0) mine = L[(size_t)ph * npad + col];
     }
     lds_barrier();
@@ -467,6 +470,7 @@ k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start
             int v = mine > other ? mine : other;
             if (col == m) v = d.x;
             mine = v;
+            last_e = d.x;
             L[(size_t)d.x * npad + col] = v;
             ring[(size_t)m * H + (((d.w >> 20) & 63) & hm)] = ((u64)(unsigned)v << 32) | (unsigned)d.x;
             box[m].x = -1;  // consumed
@@ -474,6 +478,7 @@ k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start
         lds_barrier();
         t_cur = t_nxt; t_nxt = t_nn;
     }
+    if (blockIdx.x == 0 && !loader) prev_head_out[m] = last_e;
 }
 
 
@@ -491,7 +496,7 @@ k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start
 template <int PENDL>
 __global__ void __launch_bounds__(320)
 k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-                  const int* __restrict__ prev_head, int* L, int npad, int H, int chs) {
+                  const int* __restrict__ prev_head, int* prev_head_out, int* L, int npad, int H, int chs) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int NS = 4;
     constexpr int LVR = 256;
@@ -519,6 +524,7 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
     int4 pend[PENDL];
     int lpend = 0;
     int mine = -1;
+    int last_e = -1;
     int last_store = -1000;
     if (loader) {
 #pragma unroll
@@ -530,6 +536,7 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
         lpend = lev_start[j < nlev ? j : nlev];
     } else {
         const int ph = prev_head[m];
+        last_e = ph;
         if (ph >= 0) mine = L[(size_t)ph * npad + col];
     }
     lds_barrier();
@@ -585,6 +592,7 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
                 int v = mine > other ? mine : other;
                 if (col == m) v = d.x;
                 mine = v;
+                last_e = d.x;
                 const int se6 = (d.w >> 20) & 63;
                 L[(size_t)d.x * npad + col] = v;
                 ring[(size_t)m * H + (se6 & hm)] = ((u64)(unsigned)v << 32) | (unsigned)d.x;
@@ -599,6 +607,7 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
         }
         lds_barrier();
     }
+    if (blockIdx.x == 0 && !loader) prev_head_out[m] = last_e;
 }
 
 // ---------------------------------------------------------------------------------
@@ -609,8 +618,9 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
 // lo[r][.] (checked on the CPU in tests/model_bulk.py).
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
-          const int* __restrict__ chain_start, const int* __restrict__ chain_ev,
+k_resolve(RState* st, int npad, int K, int MCAP, int Rcap,
+          const int* __restrict__ chain_start, const int* __restrict__ chain_len,
+          const int* __restrict__ chain_ev,
           int* lo, int* lopos, int* evalround, int* evalpos,
           int* lo_r, int* cur, int* unres, int* lo_next, int* pos_next, int* found) {
     __shared__ int s_min;
@@ -622,7 +632,8 @@ k_resolve(RState* st, int npad, int K, int N, int MCAP, int Rcap,
     const int iter = st->iter;
     // independent loads first (one memory round trip instead of a dependent chain)
     const int cs = chain_start[c];
-    const int clen = chain_start[c + 1] - cs;
+    const int clen = chain_len[c];  // events of member c visible to this run
+    const int N = st->N;
     int un = unres[c];
     int curc = cur[c];
     const int fnd = found[c];  // smallest candidate slot whose tally passed (INF: none)
@@ -792,7 +803,8 @@ __device__ __forceinline__ void tally_chunk(const u64 vm, const int j, const uin
 template <int NW, bool UNIT>
 __global__ void __launch_bounds__(256)
 k_tally_candidates(RState* st, int K, const int* __restrict__ unres, const int* __restrict__ cur,
-                   const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int* found,
+                   const int* __restrict__ chain_start, const int* __restrict__ chain_len,
+                   const int* __restrict__ chain_ev, int* found,
                    const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
                    const int* __restrict__ lo_r, const u64* __restrict__ Mb,
                    const uint32_t* __restrict__ stake, uint32_t tot2, int npad) {
@@ -805,7 +817,7 @@ k_tally_candidates(RState* st, int K, const int* __restrict__ unres, const int* 
     if (!unres[cm]) return;
     const int ccs = chain_start[cm];
     const int cp = cur[cm] + cj;
-    if (cp >= chain_start[cm + 1] - ccs) return;
+    if (cp >= chain_len[cm]) return;
     const int e = chain_ev[ccs + cp];
     const int mlo = st->mlo, mhi = st->mhi;
     u64* hm = s_hm[wib];
@@ -909,7 +921,8 @@ constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 template <int NW>
 __global__ void __launch_bounds__(256)
 k_tally_bits(RState* st, int K, const int* __restrict__ unres, const int* __restrict__ cur,
-             const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int* found,
+             const int* __restrict__ chain_start, const int* __restrict__ chain_len,
+             const int* __restrict__ chain_ev, int* found,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
              const int* __restrict__ lo_r, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
@@ -925,7 +938,7 @@ k_tally_bits(RState* st, int K, const int* __restrict__ unres, const int* __rest
     if (!unres[cm]) return;
     const int ccs = chain_start[cm];
     const int cp = cur[cm] + cj;
-    if (cp >= chain_start[cm + 1] - ccs) return;
+    if (cp >= chain_len[cm]) return;
     const int e = chain_ev[ccs + cp];
     const int mlo = st->mlo, mhi = st->mhi;
     int* pk = s_pk[wib];

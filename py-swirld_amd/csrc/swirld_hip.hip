@@ -34,6 +34,9 @@ struct sw_ctx {
     uint32_t tot = 0;
     std::vector<uint32_t> stake_h;
     hipStream_t stream = nullptr;
+    hipStream_t stream_cs = nullptr;   // can_see sweeps run here, ahead of the round loop
+    std::vector<hipEvent_t> cs_events;
+    int pipe = 8;                       // sub-batches per divide_rounds call (pipelining depth)
     std::string err;
 
     // host mirror of the DAG (validation, height, chains)
@@ -54,7 +57,9 @@ struct sw_ctx {
     DBuf<double> d_t;
     DBuf<u64> d_S;
     DBuf<int32_t> d_chain_start;  // npad + 1
-    DBuf<int32_t> d_prev_head;    // npad: latest divided event per member (-1 none)
+    DBuf<int32_t> d_prev_head;    // 2 x npad (ping-pong): latest divided event per member (-1 none)
+    DBuf<int32_t> d_chain_len;    // npad: events per member visible to the running round loop
+    std::vector<int32_t> blk_hmin, blk_hmax;  // height span per 4096-event block (ingest-time index)
     std::vector<int32_t> divided_head;
     DBuf<uint32_t> d_stake;       // npad
 
@@ -298,13 +303,16 @@ int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
             (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_cansee_stream<CB, MAXP, BT>), dim3(c->npad / CB), dim3(BT), g.lds, c->stream,
+    hipLaunchKernelGGL((k_cansee_stream<CB, MAXP, BT>), dim3(c->npad / CB), dim3(BT), g.lds, c->stream_cs,
                        (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, g.H, g.chs);
     return SW_OK;
 }
 
 template <int NW>
-int launch_cansee(sw_ctx* c, int nlev) {
+int launch_cansee(sw_ctx* c, int nlev, int pp) {
+    hipStream_t strm = c->stream_cs;
+    const int* ph_in = c->d_prev_head.p + (size_t)(pp & 1) * c->npad;
+    int* ph_out = c->d_prev_head.p + (size_t)((pp + 1) & 1) * c->npad;
     constexpr int CB = 16;
     if ((c->cansee_impl == 4 || c->cansee_impl == 5) && c->npad <= 256) {
         // member-per-thread kernel: npad workgroups of npad workers + one loader wave
@@ -319,7 +327,6 @@ int launch_cansee(sw_ctx* c, int nlev) {
                 (void)hipGetLastError();
             attr_set = true;
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), c->npad * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         if (c->cansee_impl == 5) {
             static bool attr_set5 = false;
             if (!attr_set5) {
@@ -327,12 +334,12 @@ int launch_cansee(sw_ctx* c, int nlev) {
                     (void)hipGetLastError();
                 attr_set5 = true;
             }
-            hipLaunchKernelGGL(k_cansee_member1b<16>, dim3(c->npad), dim3(c->npad + 64), lds + (size_t)c->npad * 4, c->stream,
-                               (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, (const int*)c->d_prev_head.p,
+            hipLaunchKernelGGL(k_cansee_member1b<16>, dim3(c->npad), dim3(c->npad + 64), lds + (size_t)c->npad * 4, strm,
+                               (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, ph_in, ph_out,
                                c->d_L.p, c->npad, std::max(H, 16), chs);
         } else
-        hipLaunchKernelGGL(k_cansee_member<16>, dim3(c->npad), dim3(c->npad + 64), lds, c->stream,
-                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, (const int*)c->d_prev_head.p,
+        hipLaunchKernelGGL(k_cansee_member<16>, dim3(c->npad), dim3(c->npad + 64), lds, strm,
+                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, ph_in, ph_out,
                            c->d_L.p, c->npad, H, chs);
     } else if (c->cansee_impl >= 2) {
         const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req, c->cansee_impl);
@@ -346,10 +353,10 @@ int launch_cansee(sw_ctx* c, int nlev) {
         else CHK((launch_cansee_stream<4, 4, 1024>(c, nlev, g)));
     } else if (c->cansee_impl == 1 && c->ring_H >= 1) {
         const size_t lds = ((size_t)c->npad * c->ring_H * CB + (size_t)c->npad * c->ring_H) * sizeof(int);
-        hipLaunchKernelGGL(k_cansee_ring<CB>, dim3(c->npad / CB), dim3(1024), lds, c->stream,
+        hipLaunchKernelGGL(k_cansee_ring<CB>, dim3(c->npad / CB), dim3(1024), lds, strm,
                            (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, c->ring_H);
     } else {
-        hipLaunchKernelGGL(k_cansee_levels<CB>, dim3(c->npad / CB), dim3(1024), 0, c->stream,
+        hipLaunchKernelGGL(k_cansee_levels<CB>, dim3(c->npad / CB), dim3(1024), 0, strm,
                            (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad);
     }
     c->ctr.kernel_launches++;
@@ -365,8 +372,9 @@ void enqueue_iteration(sw_ctx* c, std::vector<Span>* tally_spans) {
     const int tally_blocks = np * K / 4;
     const int mask_blocks = std::min(std::max(c->MCAP / 4, 1), 2048);
     const uint32_t tot2 = 2u * c->tot;
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(np), 0, c->stream, c->d_state, np, K, (int)c->N,
-                       c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(np), 0, c->stream, c->d_state, np, K,
+                       c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
+                       (const int*)c->d_chain_ev.p,
                        c->d_lo.p, c->d_lopos.p, c->d_evalround.p, c->d_evalpos.p, c->d_lo_r.p,
                        c->d_cur.p, c->d_unres.p, c->d_lo_next.p, c->d_pos_next.p, c->d_found.p);
     hipLaunchKernelGGL(k_band_masks<NW>, dim3(mask_blocks), dim3(256), 0, c->stream,
@@ -377,21 +385,21 @@ void enqueue_iteration(sw_ctx* c, std::vector<Span>* tally_spans) {
     if (c->unit_stake && c->tally_impl == 1)
         hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream,
                            c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
-                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, c->d_found.p,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p, c->d_found.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p,
                            (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const uint32_t*)c->d_Mb.p,
                            tot2, np);
     else if (c->unit_stake)
         hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream,
                            c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
-                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, c->d_found.p,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p, c->d_found.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p,
                            (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
                            (const uint32_t*)c->d_stake.p, tot2, np);
     else
         hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream,
                            c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
-                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, c->d_found.p,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p, c->d_found.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p,
                            (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
                            (const uint32_t*)c->d_stake.p, tot2, np);
@@ -429,10 +437,11 @@ int launch_batch(sw_ctx* c, std::vector<Span>* tally_spans) {
 }
 
 template <int NW>
-int run_round_loop(sw_ctx* c, int r_start, float* tally_ms_out, int* tally_launches_out) {
+int run_round_loop(sw_ctx* c, int r_start, int64_t limit, float* tally_ms_out, int* tally_launches_out) {
     const int np = c->npad, K = c->K;
     RState init{};
     init.r = r_start;
+    init.N = (int)limit;
     HIPCHK(c, hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_unres.p, 0, np * sizeof(int32_t), c->stream));
     CHK(fill_i32(c, c->d_found.p, np, SW_INF));
@@ -461,85 +470,139 @@ int run_round_loop(sw_ctx* c, int r_start, float* tally_ms_out, int* tally_launc
         int cnt = 0;
         // only the launches that did work (iterations before `done`)
         for (size_t i = 0; i < tally_spans.size() && (int)i < st.iter - 1; ++i) { ms += span_ms(tally_spans[i]); ++cnt; }
-        *tally_ms_out = ms;
-        *tally_launches_out = cnt;
+        *tally_ms_out += ms;
+        *tally_launches_out += cnt;
     }
     return SW_OK;
 }
 
+// height span of the events [a, b): from the ingest-time block index, edges by scanning
+void height_span(const sw_ctx* c, int64_t a, int64_t b, int* hmin, int* hmax) {
+    int lo = 0x7fffffff, hi = -1;
+    int64_t e = a;
+    while (e < b) {
+        if ((e & 4095) == 0 && e + 4096 <= b) {
+            lo = std::min(lo, c->blk_hmin[e >> 12]);
+            hi = std::max(hi, c->blk_hmax[e >> 12]);
+            e += 4096;
+        } else {
+            lo = std::min(lo, c->ht[e]);
+            hi = std::max(hi, c->ht[e]);
+            ++e;
+        }
+    }
+    *hmin = lo;
+    *hmax = hi;
+}
+
 template <int NW>
 int do_divide(sw_ctx* c, int64_t first, int64_t K) {
-    const int np = c->npad;
+    const int np = c->npad, n = c->n;
     c->ev_used = 0;
     Span sp_total = span_begin(c);
-    // ---- level buckets + can_see rows ----
-    int hmin = 0x7fffffff, hmax = -1;
-    {
-        // height span of the batch: from the ingest-time records when the batch is a union of
-        // whole appends (the normal case), else by scanning
-        int64_t covered = first;
-        for (const auto& a : c->appends) {
-            if (a.first == covered && a.first + a.K <= first + K) {
-                hmin = std::min(hmin, a.hmin); hmax = std::max(hmax, a.hmax); covered += a.K;
-            }
-        }
-        if (covered != first + K) {
-            hmin = 0x7fffffff; hmax = -1;
-            for (int64_t e = first; e < first + K; ++e) { hmin = std::min(hmin, c->ht[e]); hmax = std::max(hmax, c->ht[e]); }
-        }
-    }
-    const int nlev = hmax - hmin + 1;
-    CHK(dgrow(c, c->d_lev_cnt, nlev, 0));
-    CHK(dgrow(c, c->d_lev_start, nlev + 1, 0));
-    CHK(dgrow(c, c->d_lev_cursor, nlev, 0));
-    CHK(dgrow(c, c->d_desc, K, 0));
     if (c->chains_dirty) CHK(rebuild_chains(c));
-    Span sp_cs = span_begin(c);
-    HIPCHK(c, hipMemsetAsync(c->d_lev_cnt.p, 0, nlev * sizeof(int32_t), c->stream));
-    const int eb = (int)((K + 255) / 256);
-    hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, c->stream, (const int*)c->d_ht.p, (int)first, (int)K, hmin, c->d_lev_cnt.p);
-    hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, c->stream, (const int*)c->d_lev_cnt.p, nlev, c->d_lev_start.p, c->d_lev_cursor.p);
-    hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, c->stream, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
-                       (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)first, (int)K, hmin,
-                       (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
-    c->ctr.kernel_launches += 3;
-    CHK(launch_cansee<NW>(c, nlev));
-    span_end(c, sp_cs);
-    c->ctr.levels += nlev;
-
-    // ---- round loop ----
-    CHK(ensure_rounds(c, std::max(c->R, 1) + c->BATCH + 4));
-    int r_start = 0x7fffffff;
-    {
-        // members touched by this batch; a member's first event (its root) opens its chain
-        // at round 0: lo[0][m] = root, chain position 0 (swirld.py:195-198)
-        bool row0_dirty = false;
-        std::vector<char> touched(c->n, 0);
-        if (first + K == c->N) {  // dividing through the newest event: per-member heads tell everything
-            for (int m = 0; m < c->n; ++m)
-                if (c->head[m] >= first) touched[m] = 1;
-        } else {
-            for (int64_t e = first; e < first + K; ++e) touched[c->cr[e]] = 1;
+    // ---- sub-batches: the can_see sweep of sub-batch i+1 (stream_cs) overlaps the round loop
+    // of sub-batch i (main stream); a kernel boundary separates producer and consumer of a row
+    std::vector<int64_t> cut{first};
+    if (K >= 65536 && c->pipe > 1) {
+        for (int s_ = 1; s_ < c->pipe; ++s_) {
+            const int64_t bnd = ((first + K * s_ / c->pipe) >> 12) << 12;
+            if (bnd > cut.back() && bnd < first + K) cut.push_back(bnd);
         }
-        for (int m = 0; m < c->n; ++m) {
-            if (touched[m] && c->front[m] < 0) {  // the member's root is in this batch
-                c->lo0_h[m] = c->first_ev[m];
-                c->front[m] = 0;
-                row0_dirty = true;
-            }
-            if (touched[m]) r_start = std::min(r_start, c->front[m]);
-        }
-        if (r_start == 0x7fffffff) r_start = 0;
-        if (row0_dirty)
-            HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
+    cut.push_back(first + K);
+    const int S = (int)cut.size() - 1;
+    std::vector<int> hmins(S), nlevs(S);
+    int max_nlev = 1;
+    int64_t max_k = 1;
+    for (int i = 0; i < S; ++i) {
+        int hmax;
+        height_span(c, cut[i], cut[i + 1], &hmins[i], &hmax);
+        nlevs[i] = hmax - hmins[i] + 1;
+        max_nlev = std::max(max_nlev, nlevs[i]);
+        max_k = std::max(max_k, cut[i + 1] - cut[i]);
+        c->ctr.levels += nlevs[i];
+    }
+    CHK(dgrow(c, c->d_lev_cnt, max_nlev, 0));
+    CHK(dgrow(c, c->d_lev_start, max_nlev + 1, 0));
+    CHK(dgrow(c, c->d_lev_cursor, max_nlev, 0));
+    CHK(dgrow(c, c->d_desc, max_k, 0));
+    while ((int)c->cs_events.size() < S) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->cs_events.push_back(e);
+    }
+    // ---- enqueue every can_see sweep on its own stream
+    hipStream_t cs = c->stream_cs;
+    hipEvent_t cs_t0 = nullptr, cs_t1 = nullptr;
+    if (c->profiling) { cs_t0 = next_event(c); cs_t1 = next_event(c); (void)hipEventRecord(cs_t0, cs); }
+    HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+    for (int i = 0; i < S; ++i) {
+        const int64_t a = cut[i], k = cut[i + 1] - cut[i];
+        HIPCHK(c, hipMemsetAsync(c->d_lev_cnt.p, 0, nlevs[i] * sizeof(int32_t), cs));
+        const int eb = (int)((k + 255) / 256);
+        hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (int)a, (int)k, hmins[i], c->d_lev_cnt.p);
+        hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, cs, (const int*)c->d_lev_cnt.p, nlevs[i], c->d_lev_start.p, c->d_lev_cursor.p);
+        hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
+                           (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)a, (int)k, hmins[i],
+                           (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
+        c->ctr.kernel_launches += 3;
+        CHK(launch_cansee<NW>(c, nlevs[i], i));
+        HIPCHK(c, hipEventRecord(c->cs_events[i], cs));
+    }
+    if (c->profiling) (void)hipEventRecord(cs_t1, cs);
+
+    // ---- round loops, one per sub-batch, each over the events visible so far
+    CHK(ensure_rounds(c, std::max(c->R, 1) + c->BATCH + 4));
     Span sp_rl = span_begin(c);
     float tally_ms = 0.f;
     int tally_launches = 0;
-    CHK(run_round_loop<NW>(c, r_start, &tally_ms, &tally_launches));
+    int r_min = 0x7fffffff;
+    std::vector<int32_t> clen_prev(np, 0), clen(np, 0);
+    for (int m = 0; m < n; ++m) {  // members' visible chain lengths before this call
+        const int32_t* ch = c->chain_ev_h.data() + c->chain_start_h[m];
+        const int len = c->chain_start_h[m + 1] - c->chain_start_h[m];
+        clen_prev[m] = (int32_t)(std::lower_bound(ch, ch + len, (int32_t)first) - ch);
+    }
+    for (int i = 0; i < S; ++i) {
+        const int64_t limit = cut[i + 1];
+        int r_start = 0x7fffffff;
+        bool row0_dirty = false;
+        for (int m = 0; m < n; ++m) {
+            const int32_t* ch = c->chain_ev_h.data() + c->chain_start_h[m];
+            const int len = c->chain_start_h[m + 1] - c->chain_start_h[m];
+            clen[m] = (int32_t)(std::lower_bound(ch, ch + len, (int32_t)limit) - ch);
+            if (clen[m] > clen_prev[m]) {  // member touched by this sub-batch
+                if (c->front[m] < 0) {     // its root (swirld.py:195-198): lo[0][m], chain position 0
+                    c->lo0_h[m] = c->first_ev[m];
+                    c->front[m] = 0;
+                    row0_dirty = true;
+                }
+                r_start = std::min(r_start, c->front[m]);
+            }
+        }
+        if (r_start == 0x7fffffff) r_start = std::max(c->R - 1, 0);
+        r_min = std::min(r_min, r_start);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i], 0));
+        if (row0_dirty)
+            HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_chain_len.p, clen.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        CHK(run_round_loop<NW>(c, r_start, limit, &tally_ms, &tally_launches));
+        // host mirror of the per-member front round
+        const int R = c->R;
+        std::vector<int32_t> rows((size_t)std::max(R - r_start, 0) * np);
+        if (!rows.empty()) {
+            HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_lo.p + (size_t)r_start * np, rows.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        for (int m = 0; m < n; ++m)
+            for (int r = R - 1; r >= r_start; --r)
+                if (rows[(size_t)(r - r_start) * np + m] != SW_INF) { c->front[m] = std::max(c->front[m], r); break; }
+        clen_prev.swap(clen);
+    }
     span_end(c, sp_rl);
 
-    // ---- finalize ----
+    // ---- finalize: round numbers, sees-masks, witness table
     Span sp_fin = span_begin(c);
     const int R = c->R;
     CHK(ensure_rounds(c, R + 2));
@@ -547,26 +610,18 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         const int blocks = (int)std::min<int64_t>((K + 3) / 4, 8192);
         hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, c->stream, (const int*)c->d_L.p,
                            (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)first, (int)K, c->d_round.p, c->d_S.p, np);
-        const int total = (R - r_start) * np;
+        const int total = (R - r_min) * np;
         if (total > 0)
             hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                               (const int*)c->d_lo.p, R, r_start, np, c->d_wit.p);
+                               (const int*)c->d_lo.p, R, r_min, np, c->d_wit.p);
         c->ctr.kernel_launches += 2;
     }
     span_end(c, sp_fin);
-    // host mirror of the per-member front round
-    {
-        std::vector<int32_t> rows((size_t)(R - r_start) * np);
-        if (!rows.empty())
-            HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_lo.p + (size_t)r_start * np, rows.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        span_end(c, sp_total);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int m = 0; m < c->n; ++m)
-            for (int r = R - 1; r >= r_start; --r)
-                if (rows[(size_t)(r - r_start) * np + m] != SW_INF) { c->front[m] = std::max(c->front[m], r); break; }
-    }
+    span_end(c, sp_total);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_cs));
     HIPCHK(c, hipGetLastError());
-    c->sw_dirty_from = std::min(c->sw_dirty_from, std::max(r_start, 1));
+    c->sw_dirty_from = std::min(c->sw_dirty_from, std::max(r_min, 1));
     if (first + K == c->N) std::copy(c->head.begin(), c->head.end(), c->divided_head.begin());
     else for (int64_t e = first; e < first + K; ++e) c->divided_head[c->cr[e]] = (int32_t)e;
     c->divided = first + K;
@@ -578,7 +633,9 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     c->ctr.events_divided += K;
     c->ctr.rounds = R;
     if (c->profiling) {
-        c->tm.can_see_ms = span_ms(sp_cs);
+        float ms = 0.f;
+        if (cs_t0 && cs_t1) (void)hipEventElapsedTime(&ms, cs_t0, cs_t1);
+        c->tm.can_see_ms = ms;   // on its own stream: overlaps rounds_ms
         c->tm.rounds_ms = span_ms(sp_rl);
         c->tm.tally_ms = tally_ms;
         c->tm.tally_launches = tally_launches;
@@ -839,6 +896,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_BAND")) c->MCAP = std::max(64, atoi(s));
     if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
     if (const char* s = getenv("SW_GRAPH")) c->use_graph = atoi(s) != 0;
+    if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
     c->nev.assign(n_members, 0);
@@ -857,6 +915,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
 #define CHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, SW_EIO, "%s: %s", #expr, hipGetErrorString(e_)); return bail(SW_EIO); } } while (0)
     CHIP(hipSetDevice(device));
     CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CHIP(hipStreamCreateWithFlags(&c->stream_cs, hipStreamNonBlocking));
     CHIP(hipMalloc((void**)&c->d_state, sizeof(RState)));
     CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
     CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
@@ -871,7 +930,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_lo_next, np, 0));
     CCHK(dgrow(c, c->d_pos_next, np, 0));
     CCHK(dgrow(c, c->d_found, np, 0));
-    CCHK(dgrow(c, c->d_prev_head, np, 0));
+    CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
+    CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_Mb, (size_t)c->MCAP * c->nw, 0));
     CCHK(fill_i32(c, c->d_evalround.p, np, -1));
     CCHK(fill_i32(c, c->d_evalpos.p, np, 0));
@@ -902,7 +962,7 @@ int sw_destroy(sw_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
-    dfree(c->d_chain_start); dfree(c->d_prev_head); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_chain_start); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
@@ -914,6 +974,8 @@ int sw_destroy(sw_ctx* c) {
     if (c->loop_exec) (void)hipGraphExecDestroy(c->loop_exec);
     if (c->loop_graph) (void)hipGraphDestroy(c->loop_graph);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : c->cs_events) (void)hipEventDestroy(e);
+    if (c->stream_cs) (void)hipStreamDestroy(c->stream_cs);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SW_OK;
@@ -972,6 +1034,12 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         int hmin = 0x7fffffff, hmax = -1;
         for (int64_t e = N0; e < N0 + K; ++e) { hmin = std::min(hmin, c->ht[e]); hmax = std::max(hmax, c->ht[e]); }
         c->appends.push_back({N0, K, hmin, hmax});
+        c->blk_hmin.resize((size_t)((N0 + K + 4095) >> 12), 0x7fffffff);
+        c->blk_hmax.resize((size_t)((N0 + K + 4095) >> 12), -1);
+        for (int64_t e = N0; e < N0 + K; ++e) {
+            c->blk_hmin[e >> 12] = std::min(c->blk_hmin[e >> 12], c->ht[e]);
+            c->blk_hmax[e >> 12] = std::max(c->blk_hmax[e >> 12], c->ht[e]);
+        }
     }
     c->N = N0 + K;
     c->chains_dirty = true;

@@ -171,6 +171,21 @@ def test_kernel_variants_agree(pkg, monkeypatch, cansee, tally, ring_h):
         h.close()
 
 
+@pytest.mark.parametrize("pipe", ["1", "3", "8"])
+def test_pipelined_subbatches_match_oracle(pkg, monkeypatch, pipe):
+    """One big divide_rounds call is internally split into sub-batches whose can_see sweeps
+    overlap the round loop of the previous sub-batch; the split must not change anything."""
+    monkeypatch.setenv("SW_PIPE", pipe)
+    for n, N, seed, mode, p0, p1 in [(64, 150000, 90, 0, 0, 0), (200, 90000, 91, 2, 0.1, 0.05), (16, 70000, 92, 3, 0.5, 0)]:
+        stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+        o, ncs_o = oracle_run(n, stream)
+        h, ncs_h = hip_run(pkg, n, stream)
+        assert ncs_h == ncs_o
+        assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+        assert list(h.find_order(ncs_h[0])) == list(o.find_order(ncs_o[0]))
+        h.close()
+
+
 def test_full_size_properties(pkg):
     """256 members / 1M events (BASELINE.json configs[2]): properties that need no oracle.
     (a) sees-mask self bit; (b) rounds are monotone along every self-parent chain and
