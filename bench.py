@@ -126,7 +126,7 @@ def main():
             traffic = None
     dr_b, df_b = algorithmic_bytes(n, cdelta, N)
     roofline = {
-        "bound": "hbm", "kernel": "k_tally_candidates", "achieved": round(achieved, 2), "peak": 8000.0,
+        "bound": "hbm", "kernel": "k_tally_bits", "achieved": round(achieved, 2), "peak": 8000.0,
         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
         "avg_launch_us": round(avg_launch_ms * 1e3, 2), "launches": launches,
         "evals_per_launch": round(evals / launches, 1), "bytes_per_eval": bytes_per_eval,

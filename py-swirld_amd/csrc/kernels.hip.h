@@ -502,8 +502,8 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
     constexpr int LVR = 256;
     const int CH = 1 << chs;
     int4* dstage = (int4*)smem;                                   // [NS][CH]
-    int4* mbox = dstage + (size_t)NS * CH;                        // [2][npad]
-    u64* ring = (u64*)(mbox + 2 * (size_t)npad);                  // [npad][H] {value << 32 | id}
+    int4* mbox = dstage + (size_t)NS * CH;                        // [3][npad] mailboxes, 2 levels ahead
+    u64* ring = (u64*)(mbox + 3 * (size_t)npad);                  // [npad][H] {value << 32 | id}
     int* lvb = (int*)(ring + (size_t)npad * H);                   // [LVR]
     int* newest = lvb + LVR;                                      // [npad] newest chain position & 63
     const int tid = threadIdx.x;
@@ -516,7 +516,7 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
     const int hm = H - 1;
     const int total = lev_start[nlev];
     for (int i = tid; i < npad * H; i += BT) ring[i] = 0xffffffffffffffffull;
-    for (int i = tid; i < 2 * npad; i += BT) mbox[i] = make_int4(-1, -1, -1, 0);
+    for (int i = tid; i < 3 * npad; i += BT) mbox[i] = make_int4(-1, -1, -1, 0);
     for (int i = tid; i < npad; i += BT) newest[i] = 0;
     for (int i = tid; i < 2 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
     for (int i = tid; i < 128; i += BT) lvb[i] = lev_start[i < nlev ? i : nlev];
@@ -540,26 +540,29 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
         if (ph >= 0) mine = L[(size_t)ph * npad + col];
     }
     lds_barrier();
-    int t_cur = 0, t_nxt = 0;
+    int t_nxt = 0, t_nn = 0;  // loader: ends of levels lv+1 and lv+2
     if (loader) {
-        t_cur = lvb[1];
+        const int t0 = lvb[0], t1 = lvb[1];
         t_nxt = lvb[2];
-        for (int i = lvb[0] + ll; i < t_cur; i += 64) {  // mailbox of level 0
+        t_nn = lvb[3];
+        for (int i = t0 + ll; i < t_nxt; i += 64) {  // mailboxes of levels 0 and 1
             const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
-            mbox[dd.w & 1023] = dd;
+            mbox[(size_t)(i < t1 ? 0 : 1) * npad + (dd.w & 1023)] = dd;
         }
     }
     lds_barrier();
+    int4 d = make_int4(-1, -1, -1, 0);
+    if (!loader) d = mbox[m];  // level 0
+    int b_cur = 0, b_nxt = 1, b_nn = 2;  // mailbox buffers of levels lv, lv+1, lv+2
     for (int lv = 0; lv < nlev; ++lv) {
-        int4* box = mbox + (size_t)(lv & 1) * npad;
         if (loader) {
-            int4* nbox = mbox + (size_t)((lv + 1) & 1) * npad;
-            const int t_nn = lvb[(lv + 3) & (LVR - 1)];
-            for (int i = t_cur + ll; i < t_nxt; i += 64) {  // mailbox of the next level
+            const int t_n3 = lvb[(lv + 4) & (LVR - 1)];  // end of level lv+3
+            int4* nbox = mbox + (size_t)b_nn * npad;
+            for (int i = t_nxt + ll; i < t_nn; i += 64) {  // mailbox of level lv+2
                 const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
                 nbox[dd.w & 1023] = dd;
             }
-            const int need_q = t_nn > 0 ? (t_nn - 1) >> chs : 0;
+            const int need_q = t_n3 > 0 ? (t_n3 - 1) >> chs : 0;
             while (need_q + 1 >= pend_q) {
 #pragma unroll
                 for (int k = 0; k < PENDL; ++k) dstage[(size_t)(pend_q % NS) * CH + ll + 64 * k] = pend[k];
@@ -575,10 +578,9 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
                 const int j = lv + 192 + ll;
                 lpend = lev_start[j < nlev ? j : nlev];
             }
-            t_cur = t_nxt;
             t_nxt = t_nn;
+            t_nn = t_n3;
         } else {
-            const int4 d = box[m];
             if (d.x >= 0) {
                 int other = -1;
                 if (d.z >= 0) {
@@ -597,65 +599,92 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
                 L[(size_t)d.x * npad + col] = v;
                 ring[(size_t)m * H + (se6 & hm)] = ((u64)(unsigned)v << 32) | (unsigned)d.x;
                 newest[m] = se6;
-                box[m].x = -1;
+                mbox[(size_t)b_cur * npad + m].x = -1;  // consumed
             }
             // store-completion bound: at most 6 store instructions of this wave in flight, and
             // a lone store is drained explicitly six levels after it was issued
             if (__ballot(d.x >= 0)) last_store = lv;
             if (lv - last_store == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            d = mbox[(size_t)b_nxt * npad + m];  // next level's descriptor (scattered a level ago)
         }
         lds_barrier();
+        const int t = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = t;
     }
     if (blockIdx.x == 0 && !loader) prev_head_out[m] = last_e;
 }
 
 // ---------------------------------------------------------------------------------
-// Round loop, step 1 (one workgroup, one thread per member): consume the results of the
-// previous tally launch, advance the per-member cursors, commit lo[r+1] when every member
-// is resolved, enter the next round that has work, emit the next candidate list.
+// Round loop.  One iteration = k_resolve_band -> k_tally_*; ~1 iteration per round.
 // Round-synchronous form: round[e] >= r+1  <=>  SS_r(e), evaluated with the thresholds
 // lo[r][.] (checked on the CPU in tests/model_bulk.py).
+//
+// All loop state is double-buffered by iteration parity (`par`): a kernel reads buffer `par`
+// and writes buffer `1 - par`, so the resolve step can be REPLICATED in every workgroup of
+// the band kernel (each needs its results) while only workgroup 0 stores them — this removes
+// a serial single-workgroup launch from every iteration.
 // ---------------------------------------------------------------------------------
+struct LoopBufs {
+    RState* st;       // [2]
+    int* lo_r;        // [2][npad] thresholds of the round being resolved
+    int* cur;         // [2][npad] chain position of the member's next candidate window
+    int* unres;       // [2][npad] member still searching its first round-(r+1) event
+    int* lo_next;     // [2][npad] lo[r+1][c] found so far in this round
+    int* pos_next;    // [2][npad] ... and its chain position
+    int* evalround;   // [2][npad] round in which the member's chain was last exhausted
+    int* evalpos;     // [2][npad] ... and up to which position
+    int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
+};
+
+// Step 1 (replicated, one thread per member): consume the tally results, advance the
+// per-member cursors, commit lo[r+1] when every member is resolved, enter the next round that
+// has work, derive the band.  Step 2: threshold masks of the band events, Mb[k-mlo] bit c_ =
+// (L[k][c_] >= lo[r][c_]) = "the latest event of c_ that k sees has round >= r" (one wave per
+// band event, NW ballots).
+template <int NW>
 __global__ void __launch_bounds__(1024)
-k_resolve(RState* st, int npad, int K, int MCAP, int Rcap,
-          const int* __restrict__ chain_start, const int* __restrict__ chain_len,
-          const int* __restrict__ chain_ev,
-          int* lo, int* lopos, int* evalround, int* evalpos,
-          int* lo_r, int* cur, int* unres, int* lo_next, int* pos_next, int* found) {
+k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
+               const int* __restrict__ chain_start, const int* __restrict__ chain_len,
+               const int* __restrict__ chain_ev, int* lo, int* lopos,
+               const int* __restrict__ L, const int* __restrict__ cr, u64* Mb) {
     __shared__ int s_min;
     __shared__ int s_max;
     __shared__ int s_cnt;
+    __shared__ int s_thr[1024];
+    const RState* si = B.st + par;
+    RState* so = B.st + (1 - par);
+    const bool writer = blockIdx.x == 0;
     const int c = threadIdx.x;
-    if (st->done) return;
-    int r = st->r;
-    const int iter = st->iter;
+    const size_t in = (size_t)par * npad, out = (size_t)(1 - par) * npad;
+    if (si->done) {
+        if (writer && c == 0) *so = *si;
+        return;
+    }
+    const bool member = c < npad;
+    int r = si->r;
+    const int iter = si->iter;
     // independent loads first (one memory round trip instead of a dependent chain)
-    const int cs = chain_start[c];
-    const int clen = chain_len[c];  // events of member c visible to this run
-    const int N = st->N;
-    int un = unres[c];
-    int curc = cur[c];
-    const int fnd = found[c];  // smallest candidate slot whose tally passed (INF: none)
-    const int lo_r1 = (r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
-    const int lo_r2 = (r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
-    const int lopos_r1 = (r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
-    int evr_now = evalround[c], evp_now = evalpos[c];
-    int my_lo_next = (iter > 0) ? lo_next[c] : SW_INF;
-    int my_pos_next = (iter > 0) ? pos_next[c] : 0;
-    int mlo = st->mlo, mhi = st->mhi;
-    found[c] = SW_INF;
+    const int cs = member ? chain_start[c] : 0;
+    const int clen = member ? chain_len[c] : 0;  // events of member c visible to this run
+    const int N = si->N;
+    int un = member ? B.unres[in + c] : 0;
+    int curc = member ? B.cur[in + c] : 0;
+    const int fnd = member ? B.found[in + c] : SW_INF;
+    const int lo_r1 = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
+    const int lo_r2 = (member && r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
+    const int lopos_r1 = (member && r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
+    int evr_now = member ? B.evalround[in + c] : -1, evp_now = member ? B.evalpos[in + c] : 0;
+    int my_lo_next = (member && iter > 0) ? B.lo_next[in + c] : SW_INF;
+    int my_pos_next = (member && iter > 0) ? B.pos_next[in + c] : 0;
+    int thr = member ? B.lo_r[in + c] : SW_INF;
+    int mlo = si->mlo, mhi = si->mhi;
     if (iter > 0 && un) {
         if (fnd != SW_INF) {
             my_pos_next = curc + fnd;
             my_lo_next = chain_ev[cs + my_pos_next];
-            lo_next[c] = my_lo_next;
-            pos_next[c] = my_pos_next;
             un = 0;
         } else if (curc + K >= clen) {  // chain exhausted: no round-(r+1) event of c (yet)
             un = 0;
-            evalround[c] = r;
-            evalpos[c] = clen;
             evr_now = r;
             evp_now = clen;
         } else {
@@ -668,8 +697,10 @@ k_resolve(RState* st, int npad, int K, int MCAP, int Rcap,
         int lr, nx, start;
         if (iter > 0) {  // commit round r, then look at round r+1
             if (my_lo_next != SW_INF) {
-                lo[(size_t)(r + 1) * npad + c] = my_lo_next;
-                lopos[(size_t)(r + 1) * npad + c] = my_pos_next;
+                if (writer) {
+                    lo[(size_t)(r + 1) * npad + c] = my_lo_next;
+                    lopos[(size_t)(r + 1) * npad + c] = my_pos_next;
+                }
                 lr = my_lo_next;
                 start = my_pos_next;
             } else {
@@ -679,8 +710,8 @@ k_resolve(RState* st, int npad, int K, int MCAP, int Rcap,
             nx = lo_r2;
             r = r + 1;
         } else {
-            lr = (r < Rcap) ? lo[(size_t)r * npad + c] : SW_INF;
-            start = (r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
+            lr = (member && r < Rcap) ? lo[(size_t)r * npad + c] : SW_INF;
+            start = (member && r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
             nx = lo_r1;
         }
         for (;;) {  // enter the next round that has unresolved members
@@ -701,26 +732,25 @@ k_resolve(RState* st, int npad, int K, int MCAP, int Rcap,
                 if (act) atomicMin(&s_min, lr);
                 __syncthreads();
                 mlo = s_min;
-                lo_r[c] = lr;
-                lo_next[c] = SW_INF;
+                thr = lr;
+                my_lo_next = SW_INF;
                 need_mask = 1;
                 break;
             }
             ++r;  // nothing to do in this round: step to the next one (rare, incremental calls)
             lr = nx;
-            start = (r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
-            nx = (r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
+            start = (member && r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
+            nx = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
         }
     }
     if (done) un = 0;
-    unres[c] = un;
-    cur[c] = curc;
     // candidates of member c in the next tally launch: chain positions [curc, curc + K)
     const int live = un ? (clen - curc < K ? clen - curc : K) : 0;
     const int maxc = live ? chain_ev[cs + curc + live - 1] : -1;
     if (c == 0) { s_cnt = 0; s_max = -1; }
     __syncthreads();
     if (live) { atomicAdd(&s_cnt, live); atomicMax(&s_max, maxc); }
+    if (member) s_thr[c] = thr;
     __syncthreads();
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
     // (hops beyond the cap are rebuilt from their rows by the tally kernel)
@@ -737,40 +767,65 @@ k_resolve(RState* st, int npad, int K, int MCAP, int Rcap,
             need_mask = 1;
         }
     }
-    if (c == 0) {
-        st->r = r; st->done = done; st->need_mask = need_mask; st->mlo = mlo; st->mhi = mhi;
-        st->mask_from = mask_from;
-        st->iter = iter + 1; st->n_unres = nun;
-        st->evals += (u64)s_cnt;
-        if (done) st->max_round = max_round;
-        if (err) st->err = 1;
+    if (writer) {
+        if (member) {
+            B.unres[out + c] = un;
+            B.cur[out + c] = curc;
+            B.lo_next[out + c] = my_lo_next;
+            B.pos_next[out + c] = my_pos_next;
+            B.evalround[out + c] = evr_now;
+            B.evalpos[out + c] = evp_now;
+            B.lo_r[out + c] = thr;
+            B.found[out + c] = SW_INF;
+        }
+        if (c == 0) {
+            RState t = *si;
+            t.r = r; t.done = done; t.need_mask = need_mask; t.mlo = mlo; t.mhi = mhi;
+            t.mask_from = mask_from;
+            t.iter = iter + 1; t.n_unres = nun;
+            t.evals = si->evals + (u64)s_cnt;
+            if (done) t.max_round = max_round;
+            if (err) t.err = 1;
+            *so = t;
+        }
     }
-}
-
-// ---------------------------------------------------------------------------------
-// Round loop, step 2: threshold masks of the band events.  Mb[k-mlo] bit c_ =
-// (L[k][c_] >= lo[r][c_]), i.e. "the latest event of c_ that k sees has round >= r".
-// One wave per band event, NW ballots.
-// ---------------------------------------------------------------------------------
-template <int NW>
-__global__ void __launch_bounds__(256)
-k_band_masks(const RState* __restrict__ st, const int* __restrict__ L, const int* __restrict__ cr,
-             const int* __restrict__ lo_r, u64* Mb, int npad) {
-    if (st->done || !st->need_mask) return;
+    // ---- band masks
+    if (done || !need_mask) return;
     const int lane = lane_id();
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int mlo = st->mlo, mhi = st->mhi;
-    int thr[NW];
+    const int wpb = blockDim.x >> 6;
+    const int wave = blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * wpb;
+    int t_[NW];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) thr[j] = lo_r[j * 64 + lane];
-    for (int k = st->mask_from + wave; k < mhi; k += nwaves) {
-        if (k < lo_r[cr[k]]) continue;  // round[k] < r: never a valid hop this round
+    for (int j = 0; j < NW; ++j) t_[j] = s_thr[j * 64 + lane];
+    // a wave takes 8 consecutive band events per pass: the "is it a possible hop" test for all 8
+    // in one coalesced load, then the rows of up to four valid events in flight at once
+    for (int base = mask_from + wave * 8; base < mhi; base += nwaves * 8) {
+        const int kk = base + (lane & 7);
+        const bool ok = lane < 8 && kk < mhi && kk >= s_thr[cr[kk]];  // else round[k] < r: never a hop
+        u64 vm = __ballot(ok);
+        while (vm) {
+            int ks[4];
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int v = L[(size_t)k * npad + j * 64 + lane];
-            const u64 b = __ballot(v >= thr[j]);
-            if (lane == 0) Mb[(size_t)(k - mlo) * NW + j] = b;
+            for (int u = 0; u < 4; ++u) {
+                ks[u] = -1;
+                if (vm) { ks[u] = base + __ffsll((long long)vm) - 1; vm &= vm - 1; }
+            }
+            int v[4][NW];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < NW; ++j)
+                    v[u][j] = ks[u] >= 0 ? L[(size_t)ks[u] * npad + j * 64 + lane] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ks[u] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const u64 bm = __ballot(v[u][j] >= t_[j]);
+                        if (lane == 0) Mb[(size_t)(ks[u] - mlo) * NW + j] = bm;
+                    }
+                }
         }
     }
 }
@@ -802,13 +857,19 @@ __device__ __forceinline__ void tally_chunk(const u64 vm, const int j, const uin
 // Round loop, step 3: evaluate SS_r(e) for the candidate list.
 template <int NW, bool UNIT>
 __global__ void __launch_bounds__(256)
-k_tally_candidates(RState* st, int K, const int* __restrict__ unres, const int* __restrict__ cur,
+k_tally_candidates(LoopBufs B, int par, int K,
                    const int* __restrict__ chain_start, const int* __restrict__ chain_len,
-                   const int* __restrict__ chain_ev, int* found,
+                   const int* __restrict__ chain_ev,
                    const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-                   const int* __restrict__ lo_r, const u64* __restrict__ Mb,
+                   const u64* __restrict__ Mb,
                    const uint32_t* __restrict__ stake, uint32_t tot2, int npad) {
     __shared__ u64 s_hm[4][NW * 64];
+    RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
+    const size_t pb = (size_t)(1 - par) * npad;
+    const int* unres = B.unres + pb;
+    const int* cur = B.cur + pb;
+    const int* lo_r = B.lo_r + pb;
+    int* found = B.found + pb;
     if (st->done) return;
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
@@ -918,18 +979,84 @@ __device__ __forceinline__ void add8(uint32_t (&b)[PLT], const uint32_t (&x)[8])
 
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 
+
+// Bit-sliced tally, part 1: lane (g, w) adds word w of the masks of its hops (hop h belongs to
+// group h % G; pk[h] = row of hop h in `table32`, -1 = not a hop) into bit-plane counters.
+template <int NW>
+__device__ __forceinline__ void bits_accumulate(const int* pk, const uint32_t* __restrict__ table32,
+                                                uint32_t (&b)[ilog2_c(64 * NW) + 1], const int lane) {
+    constexpr int W32 = 2 * NW, G = 64 / W32, HPL = (64 * NW) / G, PLT = ilog2_c(64 * NW) + 1;
+    const int w = lane % W32, g = lane / W32;
+#pragma unroll
+    for (int p = 0; p < PLT; ++p) b[p] = 0;
+    if constexpr (HPL >= 8) {
+#pragma unroll 4
+        for (int i0 = 0; i0 < HPL; i0 += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = pk[g + G * (i0 + u)];
+                x[u] = kk >= 0 ? table32[(size_t)kk * W32 + w] : 0u;
+            }
+            add8<PLT>(b, x);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+            const int kk = pk[g + G * i];
+            const uint32_t x = kk >= 0 ? table32[(size_t)kk * W32 + w] : 0u;
+            ripple_add<PLT>(b, x, 0);
+        }
+    }
+}
+
+// part 2: add the G hop groups across lanes (bit-sliced full adders) and compare every
+// member's count with t23 = floor(2T/3); returns, in every lane (g, w), the 32-member word w
+// of "hits > 2T/3".
+template <int NW>
+__device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) + 1], const uint32_t t23) {
+    constexpr int W32 = 2 * NW, PLT = ilog2_c(64 * NW) + 1;
+#pragma unroll
+    for (int off = W32; off < 64; off <<= 1) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int p = 0; p < PLT; ++p) {
+            const uint32_t y = (uint32_t)__shfl_xor((int)b[p], off);
+            const uint32_t u = b[p] ^ y;
+            const uint32_t nc = (b[p] & y) | (u & carry);
+            b[p] = u ^ carry;
+            carry = nc;
+        }
+    }
+    uint32_t gt = 0, eq = 0xffffffffu;  // most significant plane first
+#pragma unroll
+    for (int p = PLT - 1; p >= 0; --p) {
+        const uint32_t tb = ((t23 >> p) & 1u) ? 0xffffffffu : 0u;
+        gt |= eq & b[p] & ~tb;
+        eq &= ~(b[p] ^ tb);
+    }
+    if ((t23 >> PLT) != 0) gt = 0;  // threshold beyond any possible count
+    return gt;
+}
+
 template <int NW>
 __global__ void __launch_bounds__(256)
-k_tally_bits(RState* st, int K, const int* __restrict__ unres, const int* __restrict__ cur,
+k_tally_bits(LoopBufs B, int par, int K,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
-             const int* __restrict__ chain_ev, int* found,
+             const int* __restrict__ chain_ev,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-             const int* __restrict__ lo_r, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
+             const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
     constexpr int G = 64 / W32;          // hop groups
     constexpr int HPL = (64 * NW) / G;   // hops per lane
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
     __shared__ int s_pk[4][64 * NW];
+    RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
+    const size_t pb = (size_t)(1 - par) * npad;
+    const int* unres = B.unres + pb;
+    const int* cur = B.cur + pb;
+    const int* lo_r = B.lo_r + pb;
+    int* found = B.found + pb;
     if (st->done) return;
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
@@ -962,27 +1089,7 @@ k_tally_bits(RState* st, int K, const int* __restrict__ unres, const int* __rest
     __builtin_amdgcn_wave_barrier();
     const int w = lane % W32, g = lane / W32;
     uint32_t b[PLT];
-#pragma unroll
-    for (int p = 0; p < PLT; ++p) b[p] = 0;
-    if constexpr (HPL >= 8) {
-#pragma unroll 4
-        for (int i0 = 0; i0 < HPL; i0 += 8) {
-            uint32_t x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int kk = pk[g + G * (i0 + u)];
-                x[u] = kk >= 0 ? Mb32[(size_t)kk * W32 + w] : 0u;
-            }
-            add8<PLT>(b, x);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < HPL; ++i) {
-            const int kk = pk[g + G * i];
-            const uint32_t x = kk >= 0 ? Mb32[(size_t)kk * W32 + w] : 0u;
-            ripple_add<PLT>(b, x, 0);
-        }
-    }
+    bits_accumulate<NW>(pk, Mb32, b, lane);
     if (nfar) {  // rare: hops outside the band, masks built from their rows on the fly
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
@@ -1002,29 +1109,7 @@ k_tally_bits(RState* st, int K, const int* __restrict__ unres, const int* __rest
             }
         }
     }
-    // add the G groups: bit-sliced full adders across lanes
-#pragma unroll
-    for (int off = W32; off < 64; off <<= 1) {
-        uint32_t carry = 0;
-#pragma unroll
-        for (int p = 0; p < PLT; ++p) {
-            const uint32_t y = (uint32_t)__shfl_xor((int)b[p], off);
-            const uint32_t u = b[p] ^ y;
-            const uint32_t nc = (b[p] & y) | (u & carry);
-            b[p] = u ^ carry;
-            carry = nc;
-        }
-    }
-    // hits > floor(2T/3), bit-sliced, most significant plane first
-    const uint32_t t23 = tot2 / 3u;
-    uint32_t gt = 0, eq = 0xffffffffu;
-#pragma unroll
-    for (int p = PLT - 1; p >= 0; --p) {
-        const uint32_t tb = ((t23 >> p) & 1u) ? 0xffffffffu : 0u;
-        gt |= eq & b[p] & ~tb;
-        eq &= ~(b[p] ^ tb);
-    }
-    if ((t23 >> PLT) != 0) gt = 0;  // threshold beyond any possible count
+    const uint32_t gt = bits_finish<NW>(b, tot2 / 3u);
     uint32_t cnt = (g == 0) ? __popc(gt) : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
@@ -1048,10 +1133,17 @@ k_finalize_events(const int* __restrict__ L, const int* __restrict__ cr, const i
     for (int i = wave; i < K; i += nwaves) {
         const int e = first + i;
         const int c = cr[e];
-        int a = 0, b = R - 1;  // lo[0][c] <= e always (chain start)
-        while (a < b) {
-            const int mid = (a + b + 1) >> 1;
-            if (lo[(size_t)mid * npad + c] <= e) a = mid; else b = mid - 1;
+        // 64-ary search of the (non-decreasing) column lo[.][c]: 2 dependent probes for R <= 4096
+        int a = 0, len = R;  // the answer lies in [a, a + len); lo[0][c] <= e always (chain start)
+        while (len > 1) {
+            const int stride = (len + 63) >> 6;
+            const int row = a + lane * stride;
+            const bool ok = row < a + len && lo[(size_t)row * npad + c] <= e;
+            const u64 bal = __ballot(ok);
+            const int hi = 63 - __clzll((long long)bal);
+            const int end = a + len;
+            a += hi * stride;
+            len = end - a < stride ? end - a : stride;
         }
         if (lane == 0) round[e] = a;
 #pragma unroll
@@ -1126,6 +1218,52 @@ k_voter_masks(const int* __restrict__ wit, const int* __restrict__ L, const int*
         const u64 b = __ballot(in_s);
         if (lane == 0) out[j] = b;
     }
+    if (lane == 0) atomicAdd(&fc->voter_evals, 1ull);
+}
+
+
+// Unit-stake voter masks with the bit-sliced tally (same as k_voter_masks<NW, true>).
+template <int NW>
+__global__ void __launch_bounds__(256)
+k_voter_masks_bits(const int* __restrict__ wit, const int* __restrict__ L, const int* __restrict__ lo,
+                   const uint32_t* __restrict__ S32, uint32_t tot2, int r0, int R, int npad,
+                   uint32_t* Sw32, FameCounters* fc) {
+    constexpr int W32 = 2 * NW, PLT = ilog2_c(64 * NW) + 1;
+    __shared__ int s_pk[4][64 * NW];
+    const int lane = lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int wv = blockIdx.x * 4 + wib;
+    const int total = (R - r0) * npad;
+    if (wv >= total) return;
+    const int r = r0 + wv / npad, c = wv % npad;
+    const int y = wit[(size_t)r * npad + c];
+    uint32_t* out = Sw32 + ((size_t)r * npad + c) * W32;
+    if (y < 0 || r < 1) {
+        if (lane < W32) out[lane] = 0;
+        return;
+    }
+    int* pk = s_pk[wib];
+    u64 ex[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int col = j * 64 + lane;
+        const int k = L[(size_t)y * npad + col];
+        // round[k] == r-1  <=>  lo[r-1][col] <= k < lo[r][col]
+        const bool valid = k >= lo[(size_t)(r - 1) * npad + col] && k < lo[(size_t)r * npad + col];
+        pk[col] = valid ? k : -1;
+        ex[j] = __ballot(wit[(size_t)(r - 1) * npad + col] >= 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t b[PLT];
+    bits_accumulate<NW>(pk, S32, b, lane);
+    const uint32_t gt = bits_finish<NW>(b, tot2 / 3u);
+    const int w = lane % W32;
+    uint32_t exw = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+        if ((w >> 1) == j) exw = (uint32_t)(ex[j] >> (32 * (w & 1)));
+    if (lane < W32) out[w] = gt & exw;
     if (lane == 0) atomicAdd(&fc->voter_evals, 1ull);
 }
 

@@ -92,13 +92,15 @@ struct sw_ctx {
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
+    int band_blocks = 512; // workgroups of the resolve+band kernel
 
     // round-loop graph
     struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; int K, tally_impl, BATCH, MCAP; };
     bool use_graph = true;
-    hipGraph_t loop_graph = nullptr;
-    hipGraphExec_t loop_exec = nullptr;
+    hipGraph_t loop_graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t loop_exec[3] = {nullptr, nullptr, nullptr};
     GraphKey loop_key{};
+    int64_t stat_iters = 0, stat_events = 0;  // iterations-per-event history (first-shot sizing)
 
     // profiling
     bool profiling = false;
@@ -334,7 +336,7 @@ int launch_cansee(sw_ctx* c, int nlev, int pp) {
                     (void)hipGetLastError();
                 attr_set5 = true;
             }
-            hipLaunchKernelGGL(k_cansee_member1b<16>, dim3(c->npad), dim3(c->npad + 64), lds + (size_t)c->npad * 4, strm,
+            hipLaunchKernelGGL(k_cansee_member1b<16>, dim3(c->npad), dim3(c->npad + 64), lds + (size_t)c->npad * 4 + (size_t)c->npad * 16, strm,
                                (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, ph_in, ph_out,
                                c->d_L.p, c->npad, std::max(H, 16), chs);
         } else
@@ -364,94 +366,117 @@ int launch_cansee(sw_ctx* c, int nlev, int pp) {
     return SW_OK;
 }
 
-// one iteration of the round loop = resolve -> band masks -> tally (all self-guarding on
-// the device-side state, so extra iterations after `done` are no-ops)
+LoopBufs loop_bufs(sw_ctx* c) {
+    LoopBufs B;
+    B.st = c->d_state;
+    B.lo_r = c->d_lo_r.p; B.cur = c->d_cur.p; B.unres = c->d_unres.p; B.lo_next = c->d_lo_next.p;
+    B.pos_next = c->d_pos_next.p; B.evalround = c->d_evalround.p; B.evalpos = c->d_evalpos.p;
+    B.found = c->d_found.p;
+    return B;
+}
+
+// one iteration of the round loop = (resolve + band masks) -> tally; both kernels guard on the
+// device-side state, so extra iterations after `done` are no-ops.  `par` = iteration parity
+// (which half of the double-buffered loop state is read / written).
 template <int NW>
-void enqueue_iteration(sw_ctx* c, std::vector<Span>* tally_spans) {
+void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans) {
     const int np = c->npad, K = c->K;
     const int tally_blocks = np * K / 4;
-    const int mask_blocks = std::min(std::max(c->MCAP / 4, 1), 2048);
+    const int bt = std::max(np, 256);
+    const int band_blocks = c->band_blocks;
     const uint32_t tot2 = 2u * c->tot;
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(np), 0, c->stream, c->d_state, np, K,
+    const LoopBufs B = loop_bufs(c);
+    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K,
                        c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
-                       (const int*)c->d_chain_ev.p,
-                       c->d_lo.p, c->d_lopos.p, c->d_evalround.p, c->d_evalpos.p, c->d_lo_r.p,
-                       c->d_cur.p, c->d_unres.p, c->d_lo_next.p, c->d_pos_next.p, c->d_found.p);
-    hipLaunchKernelGGL(k_band_masks<NW>, dim3(mask_blocks), dim3(256), 0, c->stream,
-                       (const RState*)c->d_state, (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                       (const int*)c->d_lo_r.p, c->d_Mb.p, np);
+                       (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, c->d_Mb.p);
     Span s{};
     if (tally_spans) s = span_begin(c);
     if (c->unit_stake && c->tally_impl == 1)
-        hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream,
-                           c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
-                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p, c->d_found.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                           (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const uint32_t*)c->d_Mb.p,
-                           tot2, np);
+        hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p,
+                           (const uint32_t*)c->d_Mb.p, tot2, np);
     else if (c->unit_stake)
-        hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream,
-                           c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
-                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p, c->d_found.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                           (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
-                           (const uint32_t*)c->d_stake.p, tot2, np);
+        hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p,
+                           (const u64*)c->d_Mb.p, (const uint32_t*)c->d_stake.p, tot2, np);
     else
-        hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream,
-                           c->d_state, K, (const int*)c->d_unres.p, (const int*)c->d_cur.p,
-                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p, c->d_found.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p,
-                           (const int*)c->d_sp.p, (const int*)c->d_lo_r.p, (const u64*)c->d_Mb.p,
-                           (const uint32_t*)c->d_stake.p, tot2, np);
+        hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p,
+                           (const u64*)c->d_Mb.p, (const uint32_t*)c->d_stake.p, tot2, np);
     if (tally_spans) { span_end(c, s); tally_spans->push_back(s); }
-    c->ctr.kernel_launches += 3;
+    c->ctr.kernel_launches += 2;
 }
 
-// the loop body as a replayable hipGraph (BATCH iterations = 3*BATCH kernel nodes); the
-// kernel arguments are frozen at capture, so the graph is rebuilt when any of them changes
+// the loop body as replayable hipGraphs of 24 / 8 / 2 iterations (2 kernel nodes each); the
+// kernel arguments are frozen at capture, so the graphs are rebuilt when any of them changes.
+// Iteration counts are even because the loop state is double-buffered by iteration parity.
+constexpr int kGraphSizes[3] = {24, 8, 2};
+
 template <int NW>
-int launch_batch(sw_ctx* c, std::vector<Span>* tally_spans) {
+int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans) {
     if (!c->use_graph || tally_spans) {
-        for (int it = 0; it < c->BATCH; ++it) enqueue_iteration<NW>(c, tally_spans);
+        for (int it = 0; it < n_iters; ++it) enqueue_iteration<NW>(c, it & 1, tally_spans);
         return SW_OK;
     }
     sw_ctx::GraphKey key;
     memset(&key, 0, sizeof key);
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
-    key.BATCH = c->BATCH; key.MCAP = c->MCAP;
-    if (!c->loop_exec || memcmp(&key, &c->loop_key, sizeof key) != 0) {
-        if (c->loop_exec) { (void)hipGraphExecDestroy(c->loop_exec); c->loop_exec = nullptr; }
-        if (c->loop_graph) { (void)hipGraphDestroy(c->loop_graph); c->loop_graph = nullptr; }
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        const int64_t launches_before = c->ctr.kernel_launches;
-        for (int it = 0; it < c->BATCH; ++it) enqueue_iteration<NW>(c, nullptr);
-        c->ctr.kernel_launches = launches_before;
-        HIPCHK(c, hipStreamEndCapture(c->stream, &c->loop_graph));
-        HIPCHK(c, hipGraphInstantiate(&c->loop_exec, c->loop_graph, nullptr, nullptr, 0));
+    key.BATCH = c->band_blocks; key.MCAP = c->MCAP;
+    if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
+        for (int g = 0; g < 3; ++g) {
+            if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
+            if (c->loop_graph[g]) { (void)hipGraphDestroy(c->loop_graph[g]); c->loop_graph[g] = nullptr; }
+        }
         c->loop_key = key;
     }
-    HIPCHK(c, hipGraphLaunch(c->loop_exec, c->stream));
-    c->ctr.kernel_launches += 3 * c->BATCH;
+    int left = n_iters;
+    for (int g = 0; g < 3; ++g) {
+        while (left >= kGraphSizes[g]) {
+            if (!c->loop_exec[g]) {
+                HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int64_t launches_before = c->ctr.kernel_launches;
+                for (int it = 0; it < kGraphSizes[g]; ++it) enqueue_iteration<NW>(c, it & 1, nullptr);
+                c->ctr.kernel_launches = launches_before;
+                HIPCHK(c, hipStreamEndCapture(c->stream, &c->loop_graph[g]));
+                HIPCHK(c, hipGraphInstantiate(&c->loop_exec[g], c->loop_graph[g], nullptr, nullptr, 0));
+            }
+            HIPCHK(c, hipGraphLaunch(c->loop_exec[g], c->stream));
+            c->ctr.kernel_launches += 2 * kGraphSizes[g];
+            left -= kGraphSizes[g];
+        }
+    }
     return SW_OK;
 }
 
 template <int NW>
-int run_round_loop(sw_ctx* c, int r_start, int64_t limit, float* tally_ms_out, int* tally_launches_out) {
+int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, float* tally_ms_out, int* tally_launches_out) {
     const int np = c->npad, K = c->K;
     RState init{};
     init.r = r_start;
     init.N = (int)limit;
     HIPCHK(c, hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_unres.p, 0, np * sizeof(int32_t), c->stream));
-    CHK(fill_i32(c, c->d_found.p, np, SW_INF));
+    HIPCHK(c, hipMemsetAsync(c->d_unres.p, 0, 2 * np * sizeof(int32_t), c->stream));
+    CHK(fill_i32(c, c->d_found.p, 2 * np, SW_INF));
     std::vector<Span> tally_spans;
     RState st{};
     int launched = 0;
+    // first shot: the predicted number of iterations for this many events (from the
+    // iterations-per-event rate of earlier runs), then short top-ups until the loop reports done
+    int shot = c->BATCH;
+    if (c->stat_iters > 0 && c->stat_events > 0) {
+        const double pred = (double)c->stat_iters / (double)c->stat_events * (double)n_new_events;
+        shot = std::max(2, (int)(pred * 0.97));
+    }
+    shot = std::min(shot, 4096) & ~1;
     for (;;) {
-        CHK(ensure_rounds(c, c->R + launched + c->BATCH + 4));
-        CHK(launch_batch<NW>(c, c->profiling ? &tally_spans : nullptr));
-        launched += c->BATCH;
+        CHK(ensure_rounds(c, c->R + launched + shot + 4));
+        CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr));
+        launched += shot;
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -460,6 +485,16 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, float* tally_ms_out, i
         // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
         if ((int64_t)launched > (int64_t)c->max_height + 2 + c->N / K + 4096)
             return fail(c, SW_EIO, "round loop did not terminate after %d iterations (r=%d)", launched, st.r);
+        shot = launched < 48 ? 8 : 4;
+    }
+    if (n_new_events >= 4096) {  // keep the rate estimate to runs where it means something
+        c->stat_iters += st.iter;
+        c->stat_events += n_new_events;
+    }
+    if (st.iter & 1) {
+        // the per-member exhaustion marks persist across runs; the next run reads half 0
+        HIPCHK(c, hipMemcpyAsync(c->d_evalround.p, c->d_evalround.p + np, np * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_evalpos.p, c->d_evalpos.p + np, np * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     }
     c->R = st.max_round + 1;
     c->ctr.tally_evals += (int64_t)st.evals;
@@ -587,7 +622,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         if (row0_dirty)
             HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_chain_len.p, clen.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        CHK(run_round_loop<NW>(c, r_start, limit, &tally_ms, &tally_launches));
+        CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], &tally_ms, &tally_launches));
         // host mirror of the per-member front round
         const int R = c->R;
         std::vector<int32_t> rows((size_t)std::max(R - r_start, 0) * np);
@@ -664,7 +699,11 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     HIPCHK(c, hipMemsetAsync(c->d_fc, 0, sizeof(FameCounters), c->stream));
     if (R > r0) {
         const int total = (R - r0) * np;
-        if (c->unit_stake)
+        if (c->unit_stake && c->tally_impl == 1)
+            hipLaunchKernelGGL(k_voter_masks_bits<NW>, dim3((total + 3) / 4), dim3(256), 0, c->stream,
+                               (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const uint32_t*)c->d_S.p,
+                               tot2, r0, R, np, (uint32_t*)c->d_Sw.p, c->d_fc);
+        else if (c->unit_stake)
             hipLaunchKernelGGL((k_voter_masks<NW, true>), dim3((total + 3) / 4), dim3(256), 0, c->stream,
                                (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const u64*)c->d_S.p,
                                (const uint32_t*)c->d_stake.p, tot2, r0, R, np, c->d_Sw.p, c->d_fc);
@@ -896,6 +935,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_BAND")) c->MCAP = std::max(64, atoi(s));
     if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
     if (const char* s = getenv("SW_GRAPH")) c->use_graph = atoi(s) != 0;
+    if (const char* s = getenv("SW_BAND_BLOCKS")) c->band_blocks = std::max(1, std::min(4096, atoi(s)));
     if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
@@ -909,6 +949,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         if (const char* s = getenv("SW_RING_H")) { int v = atoi(s); c->ring_H_req = v; if (v >= 1 && v <= H && (v & (v - 1)) == 0) H = v; }
         c->ring_H = H;
     }
+    c->BATCH = (c->BATCH + 1) & ~1;  // even: the loop state is double-buffered by iteration parity
     c->K = (c->K + 3) & ~3;  // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway)
     auto bail = [&](int rc) { g_create_error = c->err; sw_destroy(c); return rc; };
 #define CCHK(expr) do { int rc_ = (expr); if (rc_ != SW_OK) return bail(rc_); } while (0)
@@ -916,29 +957,32 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CHIP(hipSetDevice(device));
     CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CHIP(hipStreamCreateWithFlags(&c->stream_cs, hipStreamNonBlocking));
-    CHIP(hipMalloc((void**)&c->d_state, sizeof(RState)));
+    CHIP(hipMalloc((void**)&c->d_state, 2 * sizeof(RState)));
+    CHIP(hipMemset(c->d_state, 0, 2 * sizeof(RState)));
     CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
     CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
     const int np = c->npad;
     CCHK(dgrow(c, c->d_stake, np, 0));
     CHIP(hipMemcpy(c->d_stake.p, c->stake_h.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
-    CCHK(dgrow(c, c->d_evalround, np, 0));
-    CCHK(dgrow(c, c->d_evalpos, np, 0));
-    CCHK(dgrow(c, c->d_lo_r, np, 0));
-    CCHK(dgrow(c, c->d_cur, np, 0));
-    CCHK(dgrow(c, c->d_unres, np, 0));
-    CCHK(dgrow(c, c->d_lo_next, np, 0));
-    CCHK(dgrow(c, c->d_pos_next, np, 0));
-    CCHK(dgrow(c, c->d_found, np, 0));
+    CCHK(dgrow(c, c->d_evalround, 2 * np, 0));
+    CCHK(dgrow(c, c->d_evalpos, 2 * np, 0));
+    CCHK(dgrow(c, c->d_lo_r, 2 * np, 0));
+    CCHK(dgrow(c, c->d_cur, 2 * np, 0));
+    CCHK(dgrow(c, c->d_unres, 2 * np, 0));
+    CCHK(dgrow(c, c->d_lo_next, 2 * np, 0));
+    CCHK(dgrow(c, c->d_pos_next, 2 * np, 0));
+    CCHK(dgrow(c, c->d_found, 2 * np, 0));
     CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_Mb, (size_t)c->MCAP * c->nw, 0));
-    CCHK(fill_i32(c, c->d_evalround.p, np, -1));
-    CCHK(fill_i32(c, c->d_evalpos.p, np, 0));
-    CCHK(fill_i32(c, c->d_lo_r.p, np, SW_INF));
-    CCHK(fill_i32(c, c->d_cur.p, np, 0));
-    CCHK(fill_i32(c, c->d_lo_next.p, np, SW_INF));
-    CCHK(fill_i32(c, c->d_pos_next.p, np, 0));
+    CCHK(fill_i32(c, c->d_evalround.p, 2 * np, -1));
+    CCHK(fill_i32(c, c->d_evalpos.p, 2 * np, 0));
+    CCHK(fill_i32(c, c->d_lo_r.p, 2 * np, SW_INF));
+    CCHK(fill_i32(c, c->d_cur.p, 2 * np, 0));
+    CCHK(fill_i32(c, c->d_lo_next.p, 2 * np, SW_INF));
+    CCHK(fill_i32(c, c->d_pos_next.p, 2 * np, 0));
+    CCHK(fill_i32(c, c->d_found.p, 2 * np, SW_INF));
+    CHIP(hipMemsetAsync(c->d_unres.p, 0, 2 * np * sizeof(int32_t), c->stream));
     CCHK(ensure_rounds(c, 256));
     if (c->ring_H >= 1) {
         const size_t lds = ((size_t)np * c->ring_H * 16 + (size_t)np * c->ring_H) * sizeof(int);
@@ -971,8 +1015,10 @@ int sw_destroy(sw_ctx* c) {
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
-    if (c->loop_exec) (void)hipGraphExecDestroy(c->loop_exec);
-    if (c->loop_graph) (void)hipGraphDestroy(c->loop_graph);
+    for (int g = 0; g < 3; ++g) {
+        if (c->loop_exec[g]) (void)hipGraphExecDestroy(c->loop_exec[g]);
+        if (c->loop_graph[g]) (void)hipGraphDestroy(c->loop_graph[g]);
+    }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->cs_events) (void)hipEventDestroy(e);
     if (c->stream_cs) (void)hipStreamDestroy(c->stream_cs);
@@ -1104,8 +1150,8 @@ int sw_rewind(sw_ctx* c) {
     CHK(fill_i32(c, c->d_wit.p, rows, -1));
     HIPCHK(c, hipMemsetAsync(c->d_fam.p, 0xff, rows, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cons.p, 0, c->Rcap, c->stream));
-    CHK(fill_i32(c, c->d_evalround.p, c->npad, -1));
-    CHK(fill_i32(c, c->d_evalpos.p, c->npad, 0));
+    CHK(fill_i32(c, c->d_evalround.p, 2 * c->npad, -1));
+    CHK(fill_i32(c, c->d_evalpos.p, 2 * c->npad, 0));
     if (c->N) HIPCHK(c, hipMemsetAsync(c->d_round.p, 0xff, (size_t)c->N * sizeof(int32_t), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::fill(c->front.begin(), c->front.end(), -1);
