@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=150_000,
                     help="events of the same stream timed through the CPU oracle (0 = skip)")
     ap.add_argument("--contexts", type=int, default=4, help="max resident replicas of the DAG per GPU")
+    ap.add_argument("--mode", type=int, default=0, help="generator mode (0 uniform gossip = the benchmark; 1 cliques, 2 slow members, 3 stale other-parents: robustness runs)")
+    ap.add_argument("--p0", type=float, default=0.0)
+    ap.add_argument("--p1", type=float, default=0.0)
     args = ap.parse_args()
 
     import torch
@@ -61,7 +64,7 @@ def main():
 
     pkg = importlib.import_module("py-swirld_amd")
     n, N = args.members, args.events
-    stream = pkg.synth_hashgraph(n, N, args.seed + rank)  # generator: host, untimed
+    stream = pkg.synth_hashgraph(n, N, args.seed + rank, args.mode, args.p0, args.p1)  # generator: host, untimed
     n_ctx = max(1, min(args.contexts, args.steps + args.warmup))
     ctxs = []
     t_ing0 = time.perf_counter()
@@ -159,8 +162,9 @@ def main():
             "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "%d members, %d events, uniform-gossip hashgraph, one batch "
-                                   "divide_rounds + decide_fame per step" % (n, N),
+            "config": {"workload": "%d members, %d events, %s hashgraph, one batch "
+                                   "divide_rounds + decide_fame per step" % (
+                                       n, N, ["uniform-gossip", "two-clique", "slow-member", "stale-other-parent"][args.mode]),
                        "members": n, "events": N, "seed": args.seed,
                        "parallelism": "replicas x%d (no data-path collective)" % world,
                        "rounds": c1["rounds"], "ingest_s_untimed": round(ingest_s, 3),

@@ -36,7 +36,7 @@ struct sw_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream_cs = nullptr;   // can_see sweeps run here, ahead of the round loop
     std::vector<hipEvent_t> cs_events;
-    int pipe = 8;                       // sub-batches per divide_rounds call (pipelining depth)
+    int pipe = 4;                       // sub-batches per divide_rounds call (pipelining depth)
     std::string err;
 
     // host mirror of the DAG (validation, height, chains)
