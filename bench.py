@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--members", type=int, default=256)
     ap.add_argument("--events", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=150_000,
+    ap.add_argument("--cpu-sample", type=int, default=300_000,
                     help="events of the same stream timed through the CPU oracle (0 = skip)")
     ap.add_argument("--contexts", type=int, default=4, help="max resident replicas of the DAG per GPU")
     ap.add_argument("--mode", type=int, default=0, help="generator mode (0 uniform gossip = the benchmark; 1 cliques, 2 slow members, 3 stale other-parents: robustness runs)")

@@ -581,6 +581,9 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
             t_nxt = t_nn;
             t_nn = t_n3;
         } else {
+            // next level's descriptor (scattered a level ago): issued first so that its LDS
+            // latency overlaps the ring lookup below
+            const int4 dnext = mbox[(size_t)b_nxt * npad + m];
             if (d.x >= 0) {
                 int other = -1;
                 if (d.z >= 0) {
@@ -606,7 +609,7 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
             if (__ballot(d.x >= 0)) last_store = lv;
             if (lv - last_store == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            d = mbox[(size_t)b_nxt * npad + m];  // next level's descriptor (scattered a level ago)
+            d = dnext;
         }
         lds_barrier();
         const int t = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = t;

@@ -201,41 +201,51 @@ class Node:
         ev = Event(d, p, t, self.pk, s)
         return crypto.generichash(dumps(ev)), ev
 
-    def is_valid_event(self, h, ev):
-        """Signature, hash and parent checks (swirld.py:97-108)."""
+    def _signature_ok(self, ev):
         try:
             crypto.verify_detached(ev.s, dumps(ev[:-1]), ev.c)
+            return True
         except ValueError:
             return False
-        return (crypto.generichash(dumps(ev)) == h
-                and (ev.p == ()
-                     or (len(ev.p) == 2
-                         and ev.p[0] in self.hg and ev.p[1] in self.hg
-                         and self.hg[ev.p[0]].c == ev.c
-                         and self.hg[ev.p[1]].c != ev.c)))
+
+    def _parents_ok(self, ev):
+        if ev.p == ():
+            return True
+        if len(ev.p) != 2 or any(p not in self.hg for p in ev.p):
+            return False
+        mine, theirs = (self.hg[p].c for p in ev.p)
+        return mine == ev.c and theirs != ev.c
+
+    def is_valid_event(self, h, ev):
+        """Signature, hash and parent checks (swirld.py:97-108)."""
+        return self._signature_ok(ev) and crypto.generichash(dumps(ev)) == h and self._parents_ok(ev)
 
     def add_event(self, h, ev):
         """Store an event (swirld.py:114-120); it is uploaded with the next divide_rounds."""
         self.hg[h] = ev
         self.tbd.add(h)
-        self.height[h] = 0 if ev.p == () else max(self.height[p] for p in ev.p) + 1
+        self.height[h] = 1 + max(self.height[p] for p in ev.p) if ev.p else 0
         self._index[h] = len(self._ids)
         self._ids.append(h)
-        sp, op = (-1, -1) if ev.p == () else (self._index[ev.p[0]], self._index[ev.p[1]])
+        sp, op = (self._index[ev.p[0]], self._index[ev.p[1]]) if ev.p else (-1, -1)
         self._pending.append((self._mindex[ev.c], sp, op, float(ev.t), ev.s))
+
+    def _known_heights(self):
+        """{member pk -> height of the newest event of that member my head can see}: what a
+        peer needs to know to send only what I am missing (swirld.py:125-126)."""
+        return {pk: self.height[h] for pk, h in self.can_see[self.head].items()}
 
     def sync(self, pk, payload):
         """Pull-sync with `pk`; returns the new event ids in topological order
         (swirld.py:122-146)."""
-        known = {c: self.height[h] for c, h in self.can_see[self.head].items()}
-        msg = crypto.sign_open(self.network[pk](self.pk, crypto.sign(dumps(known), self.sk)), pk)
-        remote_head, remote_hg = loads(msg)
-        fresh = remote_hg.keys() - self.hg.keys()
-        new = tuple(toposort(fresh, lambda u: remote_hg[u].p))
-        for h in new:
-            ev = remote_hg[h]
-            if self.is_valid_event(h, ev):
-                self.add_event(h, ev)
+        request = crypto.sign(dumps(self._known_heights()), self.sk)
+        reply = crypto.sign_open(self.network[pk](self.pk, request), pk)
+        remote_head, remote_hg = loads(reply)
+        unknown = remote_hg.keys() - self.hg.keys()
+        new = tuple(toposort(unknown, lambda u: remote_hg[u].p))
+        for eid in new:
+            if self.is_valid_event(eid, remote_hg[eid]):
+                self.add_event(eid, remote_hg[eid])
         if self.is_valid_event(remote_head, remote_hg[remote_head]):
             h, ev = self.new_event(payload, (self.head, remote_head))
             assert self.is_valid_event(h, ev)
@@ -244,12 +254,19 @@ class Node:
         return new + (h,)
 
     def ask_sync(self, pk, info):
-        """Answer a sync request: everything the asker cannot know yet (swirld.py:148-161)."""
-        cs = loads(crypto.sign_open(info, pk))
-        subset = {h: self.hg[h] for h in bfs(
-            (self.head,),
-            lambda u: (p for p in self.hg[u].p
-                       if self.hg[p].c not in cs or self.height[p] > cs[self.hg[p].c]))}
+        """Answer a sync request with every event the asker cannot know yet: walk back from
+        my head, not descending below what the asker reported per member (swirld.py:148-161)."""
+        asker_heights = loads(crypto.sign_open(info, pk))
+
+        def missing_parents(u):
+            for p in self.hg[u].p:
+                creator = self.hg[p].c
+                if creator not in asker_heights or self.height[p] > asker_heights[creator]:
+                    yield p
+
+        subset = {}
+        for eid in bfs((self.head,), missing_parents):
+            subset[eid] = self.hg[eid]
         return crypto.sign(dumps((self.head, subset)), self.sk)
 
     def ancestors(self, c):
