@@ -116,7 +116,8 @@ int sw_get_consensus(sw_ctx* ctx, int r0, int r1, uint8_t* out);
  * (the inner test of swirld.py:211-214 / 250-252); out[K][ceil(n/64)] little-endian words. */
 int sw_get_sees_mask(sw_ctx* ctx, int64_t first, int64_t K, uint64_t* out);
 /* Diagnostic: Node.votes[voter][candidate] for voter = witness (rv, mv), candidate =
- * witness (rc, mc): -1 = no entry, 0/1 = vote (swirld.py:258-272). */
+ * witness (rc, mc): -1 = no entry, 0/1 = vote (swirld.py:258-272).  Recomputed from the voter
+ * masks with the semantics of one batch decide_fame() call; valid after sw_decide_fame. */
 int sw_get_vote(sw_ctx* ctx, int rv, int mv, int rc, int mc, int8_t* out);
 /* Node.transactions / Node.idx: total ordered so far, and a slice of the order. */
 int sw_num_ordered(sw_ctx* ctx, int64_t* out);

@@ -25,6 +25,7 @@ struct RState {
     int mlo, mhi;   // band of event indices covered by the mask table
     int mask_from;  // first band event whose mask must be (re)built in this iteration
     int N;          // events visible to this round-loop run (rows below N are complete)
+    int ncap;       // current cap of the band length (doubles when a far candidate needs a real tally)
     int iter;       // iterations executed in this call
     int n_unres;    // members still searching their first round-(r+1) event
     int max_round;  // valid when done
@@ -637,6 +638,8 @@ struct LoopBufs {
     int* evalround;   // [2][npad] round in which the member's chain was last exhausted
     int* evalpos;     // [2][npad] ... and up to which position
     int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
+    int* farslot;     // [2][npad] smallest candidate slot that was FAR (not tallied; INF: none)
+    int* force;       // [2][npad] tally the member's cursor candidate even though it is far
 };
 
 // Step 1 (replicated, one thread per member): consume the tally results, advance the
@@ -646,14 +649,17 @@ struct LoopBufs {
 // band event, NW ballots).
 template <int NW>
 __global__ void __launch_bounds__(1024)
-k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
+k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
-               const int* __restrict__ L, const int* __restrict__ cr, u64* Mb) {
+               const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb) {
     __shared__ int s_min;
     __shared__ int s_max;
     __shared__ int s_cnt;
     __shared__ int s_thr[1024];
+    __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
+    __shared__ int s_res[1024];   // ... and whether it is
+    __shared__ int s_cp[1024];    // chain_ev index of b's cursor candidate (-1: chain exhausted)
     const RState* si = B.st + par;
     RState* so = B.st + (1 - par);
     const bool writer = blockIdx.x == 0;
@@ -673,6 +679,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
     int un = member ? B.unres[in + c] : 0;
     int curc = member ? B.cur[in + c] : 0;
     const int fnd = member ? B.found[in + c] : SW_INF;
+    const int jf = member ? B.farslot[in + c] : SW_INF;
+    int frc = member ? B.force[in + c] : 0;
     const int lo_r1 = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
     const int lo_r2 = (member && r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
     const int lopos_r1 = (member && r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
@@ -681,11 +689,21 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
     int my_pos_next = (member && iter > 0) ? B.pos_next[in + c] : 0;
     int thr = member ? B.lo_r[in + c] : SW_INF;
     int mlo = si->mlo, mhi = si->mhi;
+    int ncap = si->ncap;
+    // tallies evaluated by the previous launch for this member: the slots before its first far one
+    int evaluated = 0;
+    int far_wait = 0;  // the cursor candidate is FAR: decide it by inheritance below
     if (iter > 0 && un) {
-        if (fnd != SW_INF) {
+        const int offered = clen - curc < K ? clen - curc : K;
+        evaluated = jf != SW_INF ? jf : offered;
+        if (fnd != SW_INF && fnd < jf) {
             my_pos_next = curc + fnd;
             my_lo_next = chain_ev[cs + my_pos_next];
             un = 0;
+        } else if (jf != SW_INF) {
+            curc += jf;  // the near slots before the first far one are false
+            far_wait = 1;
+            frc = 0;
         } else if (curc + K >= clen) {  // chain exhausted: no round-(r+1) event of c (yet)
             un = 0;
             evr_now = r;
@@ -693,6 +711,37 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
         } else {
             curc += K;
         }
+    }
+    // ---- far candidates (inheritance): every earlier position of c being false, the cursor
+    // candidate e has round >= r+1 iff its other-parent q has, i.e. q >= lo[r+1][creator(q)].
+    // That is known once creator(q) is resolved for this round; it is definitely false when q
+    // lies before that creator's cursor; otherwise c waits for the next iteration.  When both
+    // parents have round <= r the candidate needs a real tally: the band cap is doubled.
+    int grow = 0;
+    if (iter > 0) {
+        if (member) {
+            // a member is "resolved for round r" unless it is still searching
+            s_res[c] = !un;
+            s_ln[c] = my_lo_next != SW_INF ? my_lo_next : lo_r1;
+            s_cp[c] = curc < clen ? cs + curc : -1;
+        }
+        __syncthreads();
+        if (far_wait) {
+            const int e = chain_ev[cs + curc];
+            const int q = op[e];
+            const int b = cr[q];
+            if (s_res[b]) {
+                if (q >= s_ln[b]) { my_lo_next = e; my_pos_next = curc; un = 0; }
+                else grow = 1;
+            } else {
+                const int lb = s_cp[b] >= 0 ? chain_ev[s_cp[b]] : SW_INF;
+                if (q < lb) grow = 1;  // q precedes b's first possible round-(r+1) event
+            }
+            if (grow) {
+                if (ncap >= MCAP) frc = 1;  // cap exhausted: tally it with on-the-fly hop masks
+            }
+        }
+        if (__syncthreads_or(grow) && ncap < MCAP) ncap = ncap * 2 < MCAP ? ncap * 2 : MCAP;
     }
     int nun = __syncthreads_count(un);
     int need_mask = 0, done = 0, err = 0, max_round = 0;
@@ -738,6 +787,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
                 thr = lr;
                 my_lo_next = SW_INF;
                 need_mask = 1;
+                ncap = NEARCAP;
+                frc = 0;
                 break;
             }
             ++r;  // nothing to do in this round: step to the next one (rare, incremental calls)
@@ -752,7 +803,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
     const int maxc = live ? chain_ev[cs + curc + live - 1] : -1;
     if (c == 0) { s_cnt = 0; s_max = -1; }
     __syncthreads();
-    if (live) { atomicAdd(&s_cnt, live); atomicMax(&s_max, maxc); }
+    if (live) atomicMax(&s_max, maxc);
+    if (evaluated) atomicAdd(&s_cnt, evaluated);
     if (member) s_thr[c] = thr;
     __syncthreads();
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
@@ -760,7 +812,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
     int mask_from = mlo;
     {
         int want = s_max + 1;
-        if (want - mlo > MCAP) want = mlo + MCAP;
+        if (want - mlo > ncap) want = mlo + ncap;
         if (want > N) want = N;
         if (need_mask) {
             mhi = want > mlo ? want : mlo;
@@ -780,11 +832,14 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int MCAP, int Rcap,
             B.evalpos[out + c] = evp_now;
             B.lo_r[out + c] = thr;
             B.found[out + c] = SW_INF;
+            B.farslot[out + c] = SW_INF;
+            B.force[out + c] = frc;
         }
         if (c == 0) {
             RState t = *si;
             t.r = r; t.done = done; t.need_mask = need_mask; t.mlo = mlo; t.mhi = mhi;
             t.mask_from = mask_from;
+            t.ncap = ncap;
             t.iter = iter + 1; t.n_unres = nun;
             t.evals = si->evals + (u64)s_cnt;
             if (done) t.max_round = max_round;
@@ -864,7 +919,7 @@ k_tally_candidates(LoopBufs B, int par, int K,
                    const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                    const int* __restrict__ chain_ev,
                    const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-                   const u64* __restrict__ Mb,
+                   const int* __restrict__ op, const u64* __restrict__ Mb,
                    const uint32_t* __restrict__ stake, uint32_t tot2, int npad) {
     __shared__ u64 s_hm[4][NW * 64];
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
@@ -886,6 +941,13 @@ k_tally_candidates(LoopBufs B, int par, int K,
     const int mlo = st->mlo, mhi = st->mhi;
     u64* hm = s_hm[wib];
     const int ce = cr[e], spe = sp[e];
+    {   // FAR candidate (a parent beyond the band): decided by inheritance in k_resolve_band
+        const int ope = op[e];
+        if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && B.force[pb + cm])) {
+            if (lane == 0) atomicMin(&B.farslot[pb + cm], cj);
+            return;
+        }
+    }
     int thr[NW];
     int P[NW];
     uint32_t hits[NW];
@@ -1048,7 +1110,7 @@ k_tally_bits(LoopBufs B, int par, int K,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
              const int* __restrict__ chain_ev,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-             const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
+             const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
     constexpr int G = 64 / W32;          // hop groups
     constexpr int HPL = (64 * NW) / G;   // hops per lane
@@ -1073,6 +1135,13 @@ k_tally_bits(LoopBufs B, int par, int K,
     const int mlo = st->mlo, mhi = st->mhi;
     int* pk = s_pk[wib];
     const int ce = cr[e], spe = sp[e];
+    {   // FAR candidate (a parent beyond the band): decided by inheritance in k_resolve_band
+        const int ope = op[e];
+        if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && B.force[pb + cm])) {
+            if (lane == 0) atomicMin(&B.farslot[pb + cm], cj);
+            return;
+        }
+    }
     int thr[NW], P[NW];
     u64 farm[NW];
     u64 nfar = 0;

@@ -75,7 +75,7 @@ struct sw_ctx {
     DBuf<unsigned char> d_cons, d_newc;
     DBuf<u64> d_Sw;
     int Sw_rows = 0;
-    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force;
     DBuf<u64> d_Mb;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;
@@ -86,7 +86,8 @@ struct sw_ctx {
 
     // tuning
     int K = 32;        // candidates per member per tally launch
-    int MCAP = 0;      // band size (events)
+    int MCAP = 0;      // largest band (events) the mask table can hold
+    int NEARCAP = 0;   // band cap at round entry (doubles up to MCAP when a far candidate needs a tally)
     int BATCH = 24;    // loop iterations between host checks
     int cansee_impl = 5;  // 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
@@ -372,6 +373,8 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.lo_r = c->d_lo_r.p; B.cur = c->d_cur.p; B.unres = c->d_unres.p; B.lo_next = c->d_lo_next.p;
     B.pos_next = c->d_pos_next.p; B.evalround = c->d_evalround.p; B.evalpos = c->d_evalpos.p;
     B.found = c->d_found.p;
+    B.farslot = c->d_farslot.p;
+    B.force = c->d_force.p;
     return B;
 }
 
@@ -387,25 +390,25 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans) {
     const uint32_t tot2 = 2u * c->tot;
     const LoopBufs B = loop_bufs(c);
     hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K,
-                       c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
+                       c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, c->d_Mb.p);
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p);
     Span s{};
     if (tally_spans) s = span_begin(c);
     if (c->unit_stake && c->tally_impl == 1)
         hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
                            (const uint32_t*)c->d_Mb.p, tot2, np);
     else if (c->unit_stake)
         hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
                            (const u64*)c->d_Mb.p, (const uint32_t*)c->d_stake.p, tot2, np);
     else
         hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
                            (const u64*)c->d_Mb.p, (const uint32_t*)c->d_stake.p, tot2, np);
     if (tally_spans) { span_end(c, s); tally_spans->push_back(s); }
     c->ctr.kernel_launches += 2;
@@ -426,7 +429,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans) {
     memset(&key, 0, sizeof key);
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
-    key.BATCH = c->band_blocks; key.MCAP = c->MCAP;
+    key.BATCH = c->band_blocks; key.MCAP = c->MCAP + 7 * c->NEARCAP;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
         for (int g = 0; g < 3; ++g) {
             if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
@@ -459,9 +462,12 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     RState init{};
     init.r = r_start;
     init.N = (int)limit;
+    init.ncap = c->NEARCAP;
     HIPCHK(c, hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_unres.p, 0, 2 * np * sizeof(int32_t), c->stream));
     CHK(fill_i32(c, c->d_found.p, 2 * np, SW_INF));
+    CHK(fill_i32(c, c->d_farslot.p, 2 * np, SW_INF));
+    HIPCHK(c, hipMemsetAsync(c->d_force.p, 0, 2 * np * sizeof(int32_t), c->stream));
     std::vector<Span> tally_spans;
     RState st{};
     int launched = 0;
@@ -930,9 +936,12 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->divided_head.assign(c->npad, -1);
     c->ord_pos.assign(n_members, 0);
     c->lo0_h.assign(c->npad, SW_INF);
-    c->MCAP = std::max(128 * c->npad, 8192);
+    c->NEARCAP = std::max(64 * c->npad, 4096);
+    c->MCAP = std::max(1024 * c->npad, 65536);
     if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, atoi(s));
-    if (const char* s = getenv("SW_BAND")) c->MCAP = std::max(64, atoi(s));
+    if (const char* s = getenv("SW_BAND")) c->NEARCAP = std::max(64, atoi(s));
+    if (const char* s = getenv("SW_BAND_MAX")) c->MCAP = std::max(64, atoi(s));
+    c->MCAP = std::max(c->MCAP, c->NEARCAP);
     if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
     if (const char* s = getenv("SW_GRAPH")) c->use_graph = atoi(s) != 0;
     if (const char* s = getenv("SW_BAND_BLOCKS")) c->band_blocks = std::max(1, std::min(4096, atoi(s)));
@@ -972,6 +981,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_lo_next, 2 * np, 0));
     CCHK(dgrow(c, c->d_pos_next, 2 * np, 0));
     CCHK(dgrow(c, c->d_found, 2 * np, 0));
+    CCHK(dgrow(c, c->d_farslot, 2 * np, 0));
+    CCHK(dgrow(c, c->d_force, 2 * np, 0));
     CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_Mb, (size_t)c->MCAP * c->nw, 0));
@@ -1010,7 +1021,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
-    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_Mb);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
@@ -1256,7 +1267,60 @@ int sw_get_sees_mask(sw_ctx* c, int64_t first, int64_t K, uint64_t* out) {
     return SW_OK;
 }
 
-int sw_get_vote(sw_ctx* c, int, int, int, int, int8_t*) { return fail(c, SW_ENOTSUP, "sw_get_vote is not implemented yet"); }
+// Node.votes[voter][candidate] (swirld.py:60-61, 256-272), recomputed on the host from the
+// voter masks: the election of one candidate replayed up to the voter's round.  Batch semantics:
+// an entry exists for every voter that evaluated the candidate before it was decided.
+int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    *out = -1;
+    const int np = c->npad, nw = c->nw, n = c->n;
+    if (rc < 0 || rv >= c->R || mv < 0 || mv >= n || mc < 0 || mc >= n) return fail(c, SW_ERANGE, "witness slot outside the table");
+    if (rv <= rc) return SW_OK;
+    if (rv >= c->Sw_rows || c->sw_dirty_from <= rv) return fail(c, SW_EINVAL, "votes are available after decide_fame has seen these rounds");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int D = rv - rc;
+    std::vector<int32_t> wit((size_t)(D + 1) * np);
+    std::vector<u64> Sw((size_t)D * np * nw);
+    HIPCHK(c, hipMemcpyAsync(wit.data(), c->d_wit.p + (size_t)rc * np, wit.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(Sw.data(), c->d_Sw.p + (size_t)(rc + 1) * np * nw, Sw.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (wit[mc] < 0 || wit[(size_t)D * np + mv] < 0) return SW_OK;  // not witnesses: no entry
+    std::vector<char> V(n, 0), Vn(n, 0);
+    auto sw_bit = [&](int d, int voter, int member) {  // d = 1..D
+        return (int)((Sw[((size_t)(d - 1) * np + voter) * nw + (member >> 6)] >> (member & 63)) & 1ull);
+    };
+    for (int v = 0; v < n; ++v) V[v] = wit[(size_t)1 * np + v] >= 0 ? (char)sw_bit(1, v, mc) : 0;
+    if (D == 1) { *out = V[mv]; return SW_OK; }
+    const uint64_t tot2 = 2ull * c->tot;
+    for (int d = 2; d <= D; ++d) {
+        const int32_t* wrow = wit.data() + (size_t)d * np;
+        const bool coin_round = (d % c->coin_period) == 0;
+        int first = -1, first_v = 0;
+        std::vector<char> smv(n, 0);
+        for (int v = 0; v < n; ++v) {
+            Vn[v] = 0;
+            if (wrow[v] < 0) continue;
+            uint64_t yes = 0, all = 0;
+            for (int m = 0; m < n; ++m)
+                if (sw_bit(d, v, m)) { all += c->stake_h[m]; if (V[m]) yes += c->stake_h[m]; }
+            const uint64_t no = all - yes;
+            const int vote = !(no > yes);
+            const uint64_t t = vote ? yes : no;
+            smv[v] = 3 * t > tot2;
+            Vn[v] = (char)vote;
+            if (coin_round) { if (!smv[v]) Vn[v] = (char)(c->sig_h[(size_t)wrow[v] * 64] >> 7); }
+            else if (smv[v] && (first < 0 || wrow[v] < wrow[first])) { first = v; first_v = vote; }
+        }
+        (void)first_v;
+        if (!coin_round && first >= 0) {  // decided in this round by `first`: later voters never vote
+            if (d == D && wrow[mv] < wrow[first]) *out = Vn[mv];
+            return SW_OK;
+        }
+        if (d == D) { *out = Vn[mv]; return SW_OK; }
+        V.swap(Vn);
+    }
+    return SW_OK;
+}
 
 int sw_num_ordered(sw_ctx* c, int64_t* out) {
     if (!c || !out) return SW_EINVAL;

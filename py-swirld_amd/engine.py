@@ -128,6 +128,12 @@ class Hashgraph:
         self._chk(self._L.sw_get_consensus(self._h, r0, r1, _p(out)))
         return out
 
+    def vote(self, rv, mv, rc, mc):
+        """Node.votes[witness (rv, mv)][witness (rc, mc)]: 0 / 1, or -1 when there is no entry."""
+        v = C.c_int8()
+        self._chk(self._L.sw_get_vote(self._h, int(rv), int(mv), int(rc), int(mc), C.byref(v)))
+        return int(v.value)
+
     def transactions(self):
         n = C.c_int64()
         self._chk(self._L.sw_num_ordered(self._h, C.byref(n)))

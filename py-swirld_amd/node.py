@@ -131,19 +131,65 @@ class _FamousView(Mapping):
         return len(self._dict())
 
 
-class _VotesView(Mapping):
-    """Node.votes (swirld.py:60-61) is a diagnostic by-product of decide_fame in the reference
-    (nothing outside decide_fame reads it).  The GPU elections keep votes as per-round member
-    bitmasks and do not materialise the {voter -> {candidate -> bool}} dict."""
+class _VoterVotes(Mapping):
+    """Node.votes[y]: {candidate witness hash -> bool} of one voter."""
 
-    def __getitem__(self, h):
-        raise NotImplementedError("Node.votes is not materialised by the GPU elections")
+    def __init__(self, node, y):
+        self._n, self._y = node, y
+
+    def _slot(self, h):
+        nd = self._n
+        e = nd._index[h]
+        return int(nd._rounds()[e]), nd._mindex[nd.hg[h].c]
+
+    def __getitem__(self, x):
+        nd = self._n
+        (rv, mv), (rc, mc) = self._slot(self._y), self._slot(x)
+        wit = nd._witness_table()
+        if wit[rv, mv] != nd._index[self._y] or wit[rc, mc] != nd._index[x]:
+            raise KeyError(x)
+        v = nd._dev.vote(rv, mv, rc, mc)
+        if v < 0:
+            raise KeyError(x)
+        return bool(v)
 
     def __iter__(self):
-        return iter(())
+        nd = self._n
+        rv, mv = self._slot(self._y)
+        wit = nd._witness_table()
+        for rc in range(rv):
+            for mc in np.argsort(np.where(wit[rc] >= 0, wit[rc], np.iinfo(np.int32).max), kind="stable"):
+                if wit[rc, mc] >= 0 and nd._dev.vote(rv, mv, rc, int(mc)) >= 0:
+                    yield nd._ids[wit[rc, mc]]
 
     def __len__(self):
-        return 0
+        return sum(1 for _ in self)
+
+
+class _VotesView(Mapping):
+    """Node.votes: {voter witness -> {candidate witness -> bool}} (swirld.py:60-61).  The GPU
+    elections keep votes as per-round member bitmasks; entries are recomputed on demand
+    (sw_get_vote) with the semantics of one batch decide_fame() call: a voter has an entry for
+    every candidate it evaluated before that candidate was decided."""
+
+    def __init__(self, node):
+        self._n = node
+
+    def __getitem__(self, y):
+        if y not in self._n._index:
+            raise KeyError(y)
+        return _VoterVotes(self._n, y)
+
+    def __iter__(self):
+        nd = self._n
+        wit = nd._witness_table()
+        for r in range(1, wit.shape[0]):
+            for m in np.argsort(np.where(wit[r] >= 0, wit[r], np.iinfo(np.int32).max), kind="stable"):
+                if wit[r, m] >= 0:
+                    yield nd._ids[wit[r, m]]
+
+    def __len__(self):
+        return sum(1 for _ in self)
 
 
 class Node:
@@ -182,7 +228,7 @@ class Node:
         self.can_see = _CanSeeView(self)
         self.witnesses = _WitnessView(self)
         self.famous = _FamousView(self)
-        self.votes = _VotesView()
+        self.votes = _VotesView(self)
 
         # the node's own root event (swirld.py:75-80)
         h, ev = self.new_event(None, ())

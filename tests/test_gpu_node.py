@@ -67,6 +67,12 @@ def test_node_mainloop_matches_oracle(pkg):
         fam = o.famous_by_event
         assert dict(nd.famous) == {ids[e]: bool(fam[e]) for e in range(N) if fam[e] >= 0}
         assert nd.consensus == consensus
+        # Node.votes: every entry the view reports is an entry of the reference algorithm
+        for r in range(1, min(wit.shape[0], 6)):
+            for c_ in o.witness_order(r):
+                y = ids[wit[r, c_]]
+                for x, v in nd.votes[y].items():
+                    assert o.vote(index[y], index[x]) == int(v)
         assert [index[h] for h in nd.transactions] == list(o.transactions)
         assert all(nd.idx[h] == i for i, h in enumerate(nd.transactions))
         assert {index[h] for h in nd.tbd} == set(np.nonzero(o.tbd)[0])

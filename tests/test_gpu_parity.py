@@ -49,6 +49,37 @@ def test_hip_matches_reference_golden(pkg, name):
     h.close()
 
 
+@pytest.mark.parametrize("name", ["n4_s1_batch", "n4_s3_batch", "n16_s3_batch", "n10_s1_stake", "n64_s1_batch"])
+def test_votes_match_reference(pkg, name):
+    """Node.votes entries (every one the reference recorded, plus absent ones) for batch
+    schedules, through sw_get_vote."""
+    g = load_golden(name)
+    assert len(g["batches"]) == 1
+    h = pkg.Hashgraph(g["n"], g["stake"])
+    run_schedule(h, g)
+    rnd, cr = g["round"], g["creator"]
+    votes = g["votes"]
+    step = max(1, len(votes) // 1500)
+    have = {(int(y), int(x)) for y, x, _ in votes}
+    for y, x, v in votes[::step]:
+        assert h.vote(rnd[y], cr[y], rnd[x], cr[x]) == v
+    # pairs without an entry in the reference: decided candidates, later voters
+    wit = g["witnesses"]
+    rng = np.random.default_rng(0)
+    R = wit.shape[0]
+    checked = 0
+    for _ in range(4000):
+        rv = int(rng.integers(1, R)); rc = int(rng.integers(0, rv))
+        mv = int(rng.integers(0, g["n"])); mc = int(rng.integers(0, g["n"]))
+        y, x = wit[rv, mv], wit[rc, mc]
+        if y < 0 or x < 0 or (int(y), int(x)) in have:
+            continue
+        assert h.vote(rv, mv, rc, mc) == -1
+        checked += 1
+    assert checked > 20
+    h.close()
+
+
 def test_fork_is_refused(pkg):
     g = load_golden("n8_s11_forks")
     h = pkg.Hashgraph(g["n"])
@@ -134,18 +165,29 @@ def test_hip_weighted_stake(pkg, stake):
 
 
 def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
-    """Candidate-list width and band size only change the schedule, never the results
-    (exercises cursor retries and the out-of-band 'far hop' path)."""
-    n, N = 48, 15000
-    stream = pkg.synth_hashgraph(n, N, 60, 2, 0.2, 0.03)
-    o, ncs_o = oracle_run(n, stream)
-    for k, band in [("4", "64"), ("4", "100000"), ("32", "128")]:
+    """Candidate-list width, band cap and its growth limit only change the schedule, never the
+    results.  Small caps exercise cursor retries, FAR candidates decided by inheritance, waiting
+    members, band doubling, and (cap == limit) forced tallies with on-the-fly hop masks."""
+    cases = [(48, 15000, 60, 2, 0.2, 0.03), (24, 9000, 61, 2, 0.3, 0.004), (16, 6000, 62, 1, 0.01, 0)]
+    oracles = {}
+    for k, band, band_max in [("4", "64", None), ("4", "100000", None), ("32", "128", None),
+                              ("8", "64", "64"), ("16", "256", "512")]:
         monkeypatch.setenv("SW_TALLY_K", k)
         monkeypatch.setenv("SW_BAND", band)
-        h, ncs_h = hip_run(pkg, n, stream)
-        assert ncs_h == ncs_o
-        assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
-        h.close()
+        if band_max:
+            monkeypatch.setenv("SW_BAND_MAX", band_max)
+        else:
+            monkeypatch.delenv("SW_BAND_MAX", raising=False)
+        for case in cases:
+            n, N, seed, mode, p0, p1 = case
+            stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+            if case not in oracles:
+                oracles[case] = oracle_run(n, stream)
+            o, ncs_o = oracles[case]
+            h, ncs_h = hip_run(pkg, n, stream)
+            assert ncs_h == ncs_o
+            assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+            h.close()
 
 
 @pytest.mark.parametrize("cansee,tally,ring_h", [("0", "0", None), ("1", "0", "1"), ("1", "1", "2"), ("0", "1", None),

@@ -55,3 +55,21 @@ def test_model_matches_oracle(pkg, n, N, seed, mode, p0, p1, K, MCAP):
     new_c, p2 = check(n, cr, sp, op, sig, np.ones(n, np.int64), exp, K, MCAP)
     assert list(new_c) == list(nc)
     assert p2 == o.counters()["majority_evals"]
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,K,cap", [
+    (4, 600, 1, 0, 0, 0, 2, 8), (16, 3000, 3, 2, 0.25, 0.01, 4, 32), (16, 3000, 5, 1, 0.01, 0, 4, 24),
+    (24, 4000, 7, 2, 0.2, 0.002, 8, 64), (12, 3000, 9, 1, 0.002, 0, 4, 16),
+])
+def test_far_candidate_inheritance_model(pkg, n, N, seed, mode, p0, p1, K, cap):
+    """The far-candidate rule of the round loop (a candidate with a parent beyond the band is
+    decided by inheritance from its other-parent, waits, or doubles the band) vs the oracle."""
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    o = Oracle(n)
+    o.append_events(cr, sp, op, t, sig)
+    o.divide_rounds(0, N)
+    L, lo, stats = mb.bulk_rounds_v2(n, cr, sp, op, np.ones(n, np.int64), K=K, NEARCAP=cap)
+    rnd, S, wit = mb.finalize(n, cr, L, lo)
+    assert np.array_equal(rnd, o.round)
+    assert np.array_equal(wit, o.witnesses())
+    assert stats["waits"] > 0 and stats["grows"] > 0
