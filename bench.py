@@ -74,11 +74,15 @@ def main():
         h.append_events(*stream)  # ingest (Node.add_event): untimed
         ctxs.append(h)
     ingest_s = (time.perf_counter() - t_ing0) / n_ctx
+    for h in ctxs:  # set-up: every resident context builds its launch graphs once, then forgets the results
+        h.divide_rounds(0, N)
+        h.decide_fame()
+        h.rewind()
 
     def one_step(i):
         h = ctxs[i % n_ctx]
         if i >= n_ctx:
-            h.rewind()
+            h.rewind()  # inside the timed bracket when a context is reused
         h.divide_rounds(0, N)
         return h.decide_fame()
 

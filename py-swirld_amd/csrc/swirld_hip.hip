@@ -964,8 +964,21 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
 #define CCHK(expr) do { int rc_ = (expr); if (rc_ != SW_OK) return bail(rc_); } while (0)
 #define CHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, SW_EIO, "%s: %s", #expr, hipGetErrorString(e_)); return bail(SW_EIO); } } while (0)
     CHIP(hipSetDevice(device));
-    CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CHIP(hipStreamCreateWithFlags(&c->stream_cs, hipStreamNonBlocking));
+    {
+        // the round loop is the critical path: its stream gets the highest priority, the can_see
+        // sweeps (which have slack when pipelined) the lowest
+        int least = 0, greatest = 0;
+        const char* pe = getenv("SW_PRIO");
+        const bool use_prio = !pe || atoi(pe) != 0;
+        if (use_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            CHIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+            CHIP(hipStreamCreateWithPriority(&c->stream_cs, hipStreamNonBlocking, least));
+        } else {
+            (void)hipGetLastError();
+            CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            CHIP(hipStreamCreateWithFlags(&c->stream_cs, hipStreamNonBlocking));
+        }
+    }
     CHIP(hipMalloc((void**)&c->d_state, 2 * sizeof(RState)));
     CHIP(hipMemset(c->d_state, 0, 2 * sizeof(RState)));
     CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
