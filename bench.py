@@ -113,10 +113,13 @@ def main():
     c0 = h.counters()
     h.divide_rounds(0, N)
     tm_dr = h.timings()
-    h.decide_fame()
+    new_c_prof = h.decide_fame()
     tm = h.timings()
     c1 = h.counters()
     h.set_profiling(False)
+    t_fo = time.perf_counter()
+    ordered = h.find_order(new_c_prof)   # N1 (outside the metric): reported for information only
+    find_order_ms = (time.perf_counter() - t_fo) * 1e3
     cdelta = {k: c1[k] - c0[k] for k in c1}
     cdelta_far = cdelta.get("far_hops", 0)
     evals = c1["tally_evals"] - c0["tally_evals"]
@@ -172,7 +175,8 @@ def main():
                        "members": n, "events": N, "seed": args.seed,
                        "parallelism": "replicas x%d (no data-path collective)" % world,
                        "rounds": c1["rounds"], "ingest_s_untimed": round(ingest_s, 3),
-                       "new_c_last_step": int(len(new_c))},
+                       "new_c_last_step": int(len(new_c)),
+                       "find_order_ms_untimed": round(find_order_ms, 2), "events_ordered": int(len(ordered))},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

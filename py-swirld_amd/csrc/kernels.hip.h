@@ -1550,6 +1550,82 @@ k_order_times(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, in
     if (lane == 0) ts[idx] = .5 * (r1 + r2);
 }
 
+
+// whitening key of a decided round (swirld.py:285): XOR of its famous witnesses' signatures
+__global__ void k_order_white(const int* __restrict__ fw_ev, const int* __restrict__ fw_off,
+                              const unsigned char* __restrict__ sig, unsigned char* white) {
+    const int ri = blockIdx.x, b = threadIdx.x;  // 64 threads = 64 signature bytes
+    unsigned char w = 0;
+    for (int i = fw_off[ri]; i < fw_off[ri + 1]; ++i) w ^= sig[(size_t)fw_ev[i] * 64 + b];
+    white[(size_t)ri * 64 + b] = w;
+}
+
+// final order inside a round (swirld.py:306): sort by (consensus timestamp, whitened signature).
+// One workgroup per round, bitonic sort in LDS on (ts, first 8 key bytes as a big-endian
+// integer); a round with more than SORT_CAP events, or with two events equal in both (the
+// remaining 56 key bytes would have to decide), is flagged and sorted by the host instead.
+constexpr int SORT_CAP = 4096;
+__global__ void __launch_bounds__(1024)
+k_order_sort(const int* __restrict__ acc_ev, const long long* __restrict__ acc_off,
+             const double* __restrict__ ts, const unsigned char* __restrict__ sig,
+             const unsigned char* __restrict__ white, int* out_ev, int* host_flag) {
+    __shared__ double s_ts[SORT_CAP];
+    __shared__ u64 s_k8[SORT_CAP];
+    __shared__ int s_ev[SORT_CAP];
+    const int ri = blockIdx.x, tid = threadIdx.x;
+    const long long a0 = acc_off[ri];
+    const int cnt = (int)(acc_off[ri + 1] - a0);
+    if (cnt > SORT_CAP) {
+        if (tid == 0) host_flag[ri] = 1;
+        return;
+    }
+    int m = 1;
+    while (m < cnt) m <<= 1;
+    u64 wk = 0;
+    for (int b = 0; b < 8; ++b) wk = (wk << 8) | white[(size_t)ri * 64 + b];
+    for (int i = tid; i < m; i += 1024) {
+        if (i < cnt) {
+            const int e = acc_ev[a0 + i];
+            u64 k = 0;
+            for (int b = 0; b < 8; ++b) k = (k << 8) | sig[(size_t)e * 64 + b];
+            s_ts[i] = ts[a0 + i];
+            s_k8[i] = k ^ wk;
+            s_ev[i] = e;
+        } else {
+            s_ts[i] = __longlong_as_double(0x7ff0000000000000ll);  // +inf padding sorts last
+            s_k8[i] = ~0ull;
+            s_ev[i] = 0x7fffffff;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const double ta = s_ts[i], tb = s_ts[l];
+                    const u64 ka = s_k8[i], kb = s_k8[l];
+                    const int ea = s_ev[i], eb = s_ev[l];
+                    const bool gt = ta > tb || (ta == tb && (ka > kb || (ka == kb && ea > eb)));
+                    if (gt == up) {
+                        s_ts[i] = tb; s_ts[l] = ta;
+                        s_k8[i] = kb; s_k8[l] = ka;
+                        s_ev[i] = eb; s_ev[l] = ea;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int tie = 0;
+    for (int i = tid; i < cnt; i += 1024) {
+        out_ev[a0 + i] = s_ev[i];
+        if (i + 1 < cnt && s_ts[i] == s_ts[i + 1] && s_k8[i] == s_k8[i + 1]) tie = 1;
+    }
+    if (__syncthreads_or(tie) && tid == 0) host_flag[ri] = 1;
+}
+
 __global__ void k_fill_i32(int* p, size_t n, int v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;

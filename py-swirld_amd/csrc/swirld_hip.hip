@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -114,7 +115,9 @@ struct sw_ctx {
     std::vector<int32_t> ord_pos;            // per member: chain positions already ordered
     std::vector<unsigned char> sig_h;        // host copy of the signatures (whitening, sort key)
     std::vector<int32_t> chain_start_h, chain_ev_h;
-    DBuf<int32_t> d_fw_ev, d_fw_off, d_q, d_acc_ev, d_acc_ri;
+    DBuf<int32_t> d_fw_ev, d_fw_off, d_q, d_acc_ev, d_acc_ri, d_sorted, d_hostflag;
+    DBuf<long long> d_acc_off;
+    DBuf<unsigned char> d_white;
     DBuf<double> d_ts;
     int* d_err = nullptr;
 };
@@ -776,6 +779,15 @@ int get_round_rows(sw_ctx* c, const T* src, int r0, int r1, T* out, T absent) {
 template <int NW>
 int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, int64_t cap, int64_t* n_out) {
     const int np = c->npad, n = c->n;
+    const bool dbg = getenv("SW_DEBUG_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(c->stream);
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[find_order] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+        T0 = t;
+    };
     std::sort(rounds.begin(), rounds.end());  // sorted(new_c), swirld.py:283
     rounds.erase(std::unique(rounds.begin(), rounds.end()), rounds.end());
     const int nr = (int)rounds.size();
@@ -814,6 +826,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     std::vector<int32_t> q((size_t)nr * np);
     HIPCHK(c, hipMemcpyAsync(q.data(), c->d_q.p, q.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap("bounds");
     // newly ordered chain segments per round (tbd = everything at or after ord_pos)
     std::vector<int32_t> ord = c->ord_pos;
     std::vector<int32_t> acc_ev, acc_ri;
@@ -830,7 +843,9 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         acc_off[i + 1] = (int64_t)acc_ev.size();
     }
     const int64_t n_acc = (int64_t)acc_ev.size();
+    lap("segments");
     std::vector<double> ts((size_t)n_acc);
+    std::vector<int32_t> sorted((size_t)n_acc), hostflag(nr, 0);
     if (n_acc) {
         CHK(dgrow(c, c->d_acc_ev, n_acc, 0));
         CHK(dgrow(c, c->d_acc_ri, n_acc, 0));
@@ -844,18 +859,49 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
                            (const double*)c->d_t.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, np,
                            c->d_ts.p, c->d_err);
         c->ctr.kernel_launches++;
+        // device sort of every round's segment by (ts, first 8 whitened key bytes)
+        CHK(dgrow(c, c->d_white, (size_t)nr * 64, 0));
+        CHK(dgrow(c, c->d_acc_off, nr + 1, 0));
+        CHK(dgrow(c, c->d_sorted, n_acc, 0));
+        CHK(dgrow(c, c->d_hostflag, nr, 0));
+        std::vector<long long> acc_off_ll(acc_off.begin(), acc_off.end());
+        HIPCHK(c, hipMemcpyAsync(c->d_acc_off.p, acc_off_ll.data(), (nr + 1) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_hostflag.p, 0, nr * sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_order_white, dim3(nr), dim3(64), 0, c->stream, (const int*)c->d_fw_ev.p, (const int*)c->d_fw_off.p,
+                           (const unsigned char*)c->d_sig.p, c->d_white.p);
+        hipLaunchKernelGGL(k_order_sort, dim3(nr), dim3(1024), 0, c->stream, (const int*)c->d_acc_ev.p,
+                           (const long long*)c->d_acc_off.p, (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p,
+                           (const unsigned char*)c->d_white.p, c->d_sorted.p, c->d_hostflag.p);
+        c->ctr.kernel_launches += 2;
         int err = 0;
-        HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_ts.p, n_acc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sorted.data(), c->d_sorted.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hostflag.data(), c->d_hostflag.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         if (err) return fail(c, SW_ERANGE, "find_order: an event is seen by a single famous witness (IndexError at swirld.py:305)");
+        bool any_flag = false;
+        if (getenv("SW_ORDER_HOST")) std::fill(hostflag.begin(), hostflag.end(), 1);  // test hook: host sort
+        for (int i = 0; i < nr; ++i) any_flag = any_flag || hostflag[i];
+        if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts
+            HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_ts.p, n_acc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     }
+    lap("times+sort");
     // final order inside each round: (consensus timestamp, whitened signature), swirld.py:306
     struct Item { double ts; uint64_t k8; int32_t ev; };
     int64_t produced = 0;
     std::vector<Item> items;
     for (int i = 0; i < nr; ++i) {
+        if (!hostflag[i]) {  // sorted on the device
+            for (int64_t a = acc_off[i]; a < acc_off[i + 1]; ++a) {
+                c->transactions.push_back(sorted[a]);
+                if (out_events && produced < cap) out_events[produced] = sorted[a];
+                ++produced;
+            }
+            continue;
+        }
         unsigned char white[64] = {0};  // swirld.py:285
         for (int j = fw_off[i]; j < fw_off[i + 1]; ++j)
             for (int b = 0; b < 64; ++b) white[b] ^= c->sig_h[(size_t)fw_ev[j] * 64 + b];
@@ -883,6 +929,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
             ++produced;
         }
     }
+    lap("sort");
     c->ord_pos.swap(ord);
     if (n_out) *n_out = produced;
     if (produced > cap) return fail(c, SW_ERANGE, "find_order: out_events capacity %lld < %lld", (long long)cap, (long long)produced);
@@ -1039,6 +1086,7 @@ int sw_destroy(sw_ctx* c) {
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
+    dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_acc_off); dfree(c->d_white);
     for (int g = 0; g < 3; ++g) {
         if (c->loop_exec[g]) (void)hipGraphExecDestroy(c->loop_exec[g]);
         if (c->loop_graph[g]) (void)hipGraphDestroy(c->loop_graph[g]);

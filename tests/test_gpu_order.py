@@ -48,3 +48,24 @@ def test_find_order_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk):
         assert list(h.find_order(nch)) == list(o.find_order(nco))
     assert np.array_equal(h.transactions(), o.transactions)
     h.close()
+
+
+def test_host_sort_fallback_matches(pkg, monkeypatch):
+    """The per-round device sort falls back to a host sort for oversize rounds and for
+    (timestamp, 8-byte key) ties; force that path and compare."""
+    from oracle.oracle import Oracle
+    monkeypatch.setenv("SW_ORDER_HOST", "1")
+    n, N = 32, 20000
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 99)
+    t = np.floor(t / 9.0)  # heavy timestamp ties
+    o, h = Oracle(n), pkg.Hashgraph(n)
+    for d in (o, h):
+        d.append_events(cr, sp, op, t, sig)
+        d.divide_rounds(0, N)
+    nco, nch = o.decide_fame(), h.decide_fame()
+    assert list(h.find_order(nch)) == list(o.find_order(nco))
+    monkeypatch.delenv("SW_ORDER_HOST")
+    h2 = pkg.Hashgraph(n)
+    h2.append_events(cr, sp, op, t, sig)
+    h2.divide_rounds(0, N)
+    assert list(h2.find_order(h2.decide_fame())) == list(o.transactions)
