@@ -49,22 +49,19 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rep_mod = importlib.import_module("py-swirld_amd.replicas")
+    rank, local_rank, world = rep_mod.dist_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # N > 1: independent replicas, one per GPU; RCCL only for the barrier and the max-over-ranks time
+    rep = rep_mod.Replicas(backend="nccl", device=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("py-swirld_amd")
     n, N = args.members, args.events
-    stream = pkg.synth_hashgraph(n, N, args.seed + rank, args.mode, args.p0, args.p1)  # generator: host, untimed
+    stream = pkg.synth_hashgraph(n, N, rep_mod.replica_seed(args.seed, rank), args.mode, args.p0, args.p1)  # host, untimed
     n_ctx = max(1, min(args.contexts, args.steps + args.warmup))
     ctxs = []
     t_ing0 = time.perf_counter()
@@ -87,8 +84,7 @@ def main():
         return h.decide_fame()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        rep.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -98,11 +94,7 @@ def main():
     for i in range(args.warmup, args.warmup + args.steps):
         new_c = one_step(i)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = rep.max_over_ranks(time.perf_counter() - t0)
     ms_per_step = dt / args.steps * 1e3
     value = world * N * args.steps / dt
 
@@ -180,9 +172,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rep.close()
 
 
 if __name__ == "__main__":

@@ -1460,10 +1460,11 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
 __global__ void __launch_bounds__(1024)
 k_order_bounds(const int* __restrict__ fw_ev, const int* __restrict__ fw_off, const int* __restrict__ L,
                const int* __restrict__ cr, const uint32_t* __restrict__ stake, uint32_t tot,
-               const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int npad, int* q) {
+               const int* __restrict__ chain_start, const int* __restrict__ chain_cnt,
+               const int* __restrict__ chain_ev, int npad, int* q) {
     const int ri = blockIdx.x, c = threadIdx.x;
     const int f0 = fw_off[ri], f1 = fw_off[ri + 1];
-    const int cs = chain_start[c], clen = chain_start[c + 1] - cs;
+    const int cs = chain_start[c], clen = chain_cnt[c];
     int a = 0, b = clen;  // invariant: positions < a are accepted, positions >= b are not
     while (a < b) {
         const int mid = (a + b) >> 1;
@@ -1624,6 +1625,11 @@ k_order_sort(const int* __restrict__ acc_ev, const long long* __restrict__ acc_o
         if (i + 1 < cnt && s_ts[i] == s_ts[i + 1] && s_k8[i] == s_k8[i + 1]) tie = 1;
     }
     if (__syncthreads_or(tie) && tid == 0) host_flag[ri] = 1;
+}
+
+__global__ void k_scatter_i32(const int* __restrict__ idx, const int* __restrict__ val, int n, int* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = val[i];
 }
 
 __global__ void k_fill_i32(int* p, size_t n, int v) {

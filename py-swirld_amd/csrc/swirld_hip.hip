@@ -50,14 +50,17 @@ struct sw_ctx {
     bool has_forks = false;
     int max_height = 0;
     int64_t N = 0, cap = 0, divided = 0;
-    bool chains_dirty = true;
 
     // device: events
     DBuf<int32_t> d_cr, d_sp, d_op, d_ht, d_seq, d_round, d_L, d_chain_ev;
     DBuf<unsigned char> d_coin, d_sig;
     DBuf<double> d_t;
     DBuf<u64> d_S;
-    DBuf<int32_t> d_chain_start;  // npad + 1
+    DBuf<int32_t> d_chain_start;  // npad: offset of each member's segment in the chain pool
+    DBuf<int32_t> d_chain_cnt;    // npad: events per member (segments have slack: geometric growth)
+    DBuf<int32_t> d_scat_idx, d_scat_val;
+    std::vector<int32_t> chain_cap;   // per member: capacity of its segment
+    int64_t pool_used = 0;             // ints of the chain pool handed out
     DBuf<int32_t> d_prev_head;    // 2 x npad (ping-pong): latest divided event per member (-1 none)
     DBuf<int32_t> d_chain_len;    // npad: events per member visible to the running round loop
     std::vector<int32_t> blk_hmin, blk_hmax;  // height span per 4096-event block (ingest-time index)
@@ -201,7 +204,6 @@ int ensure_events(sw_ctx* c, int64_t need) {
     CHK(dgrow(c, c->d_sig, (size_t)nc * 64, keep * 64));
     CHK(dgrow(c, c->d_S, (size_t)nc * c->nw, keep * c->nw));
     CHK(dgrow(c, c->d_L, (size_t)nc * c->npad, keep * c->npad));
-    CHK(dgrow(c, c->d_chain_ev, nc, 0));
     c->cap = nc;
     return SW_OK;
 }
@@ -260,25 +262,88 @@ float span_ms(const Span& s) {
     return ms;
 }
 
-int rebuild_chains(sw_ctx* c) {
-    // per-member self-parent chains as CSR (counting sort by creator; index order == chain
-    // order for a fork-free DAG).
+// Per-member self-parent chains (index order == chain order for a fork-free DAG): every member
+// owns a segment of a pool, chain_ev[chain_start[m] + p] = its p-th event.  Segments have slack
+// and grow geometrically (a full segment moves to the end of the pool), so appending events
+// costs O(new events), not O(all events); bulk appends rebuild the pool compactly.
+int upload_chain_index(sw_ctx* c) {
     const int np = c->npad;
-    std::vector<int32_t> start(np + 1, 0);
-    for (int64_t e = 0; e < c->N; ++e) start[c->cr[e] + 1]++;
-    for (int m = 0; m < np; ++m) start[m + 1] += start[m];
-    std::vector<int32_t> fillp(start.begin(), start.end() - 1);
-    std::vector<int32_t> ev((size_t)c->N);
-    for (int64_t e = 0; e < c->N; ++e) ev[fillp[c->cr[e]]++] = (int32_t)e;
-    CHK(dgrow(c, c->d_chain_start, np + 1, 0));
-    HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, start.data(), (np + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    if (c->N)
-        HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p, ev.data(), (size_t)c->N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, c->chain_start_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    std::vector<int32_t> cnt(np, 0);
+    std::copy(c->nev.begin(), c->nev.end(), cnt.begin());
+    HIPCHK(c, hipMemcpyAsync(c->d_chain_cnt.p, cnt.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->chain_start_h.swap(start);
-    c->chain_ev_h.swap(ev);
-    c->chains_dirty = false;
     return SW_OK;
+}
+
+int rebuild_chains(sw_ctx* c) {
+    const int np = c->npad, n = c->n;
+    std::vector<int32_t> cnt(n, 0);
+    for (int64_t e = 0; e < c->N; ++e) cnt[c->cr[e]]++;
+    c->chain_start_h.assign(np, 0);
+    c->chain_cap.assign(n, 0);
+    int64_t off = 0;
+    for (int m = 0; m < n; ++m) {
+        c->chain_start_h[m] = (int32_t)off;
+        c->chain_cap[m] = cnt[m] + cnt[m] / 4 + 16;
+        off += c->chain_cap[m];
+    }
+    if (off > 0x7fffffff) return fail(c, SW_ERANGE, "chain pool exceeds 2^31 entries");
+    c->pool_used = off;
+    c->chain_ev_h.assign((size_t)off, -1);
+    std::vector<int32_t> fillp(n, 0);
+    for (int64_t e = 0; e < c->N; ++e) {
+        const int m = c->cr[e];
+        c->chain_ev_h[(size_t)c->chain_start_h[m] + fillp[m]++] = (int32_t)e;
+    }
+    CHK(dgrow(c, c->d_chain_ev, (size_t)off + (size_t)off / 2 + 1024, 0));
+    if (off)
+        HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p, c->chain_ev_h.data(), (size_t)off * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    return upload_chain_index(c);
+}
+
+// events [N0, N0 + K) were just stored: add them to their members' segments
+int extend_chains(sw_ctx* c, int64_t N0, int64_t K) {
+    std::vector<int32_t> sidx, sval;
+    sidx.reserve(K); sval.reserve(K);
+    std::vector<int32_t> filled(c->n);  // chain length before this append
+    for (int m = 0; m < c->n; ++m) filled[m] = c->nev[m];
+    for (int64_t e = N0; e < N0 + K; ++e) filled[c->cr[e]]--;
+    for (int64_t e = N0; e < N0 + K; ++e) {
+        const int m = c->cr[e];
+        if (filled[m] == c->chain_cap[m]) {  // segment full: move it to the end of the pool, doubled
+            const int32_t ncap = std::max(16, 2 * c->chain_cap[m]);
+            if (c->pool_used + ncap > 0x7fffffff) return fail(c, SW_ERANGE, "chain pool exceeds 2^31 entries");
+            const int64_t noff = c->pool_used;
+            c->chain_ev_h.resize((size_t)(noff + ncap), -1);
+            std::copy(c->chain_ev_h.begin() + c->chain_start_h[m], c->chain_ev_h.begin() + c->chain_start_h[m] + filled[m],
+                      c->chain_ev_h.begin() + noff);
+            CHK(dgrow(c, c->d_chain_ev, (size_t)(noff + ncap) * 2, (size_t)c->pool_used));
+            if (filled[m])
+                HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p + noff, c->d_chain_ev.p + c->chain_start_h[m], (size_t)filled[m] * sizeof(int32_t),
+                                         hipMemcpyDeviceToDevice, c->stream));
+            // entries of this member appended earlier in this call are still pending in the scatter
+            // list: re-target them to the new segment
+            const int32_t old0 = c->chain_start_h[m], old1 = old0 + c->chain_cap[m];
+            for (auto& at : sidx)
+                if (at >= old0 && at < old1) at += (int32_t)(noff - old0);
+            c->chain_start_h[m] = (int32_t)noff;
+            c->chain_cap[m] = ncap;
+            c->pool_used = noff + ncap;
+        }
+        const int32_t at = c->chain_start_h[m] + filled[m]++;
+        c->chain_ev_h[at] = (int32_t)e;
+        sidx.push_back(at);
+        sval.push_back((int32_t)e);
+    }
+    CHK(dgrow(c, c->d_scat_idx, K, 0));
+    CHK(dgrow(c, c->d_scat_val, K, 0));
+    HIPCHK(c, hipMemcpyAsync(c->d_scat_idx.p, sidx.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_scat_val.p, sval.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scatter_i32, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_scat_idx.p,
+                       (const int*)c->d_scat_val.p, (int)K, c->d_chain_ev.p);
+    c->ctr.kernel_launches++;
+    return upload_chain_index(c);
 }
 
 // geometry of the streaming can_see kernel for this member count
@@ -544,7 +609,6 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     const int np = c->npad, n = c->n;
     c->ev_used = 0;
     Span sp_total = span_begin(c);
-    if (c->chains_dirty) CHK(rebuild_chains(c));
     // ---- sub-batches: the can_see sweep of sub-batch i+1 (stream_cs) overlaps the round loop
     // of sub-batch i (main stream); a kernel boundary separates producer and consumer of a row
     std::vector<int64_t> cut{first};
@@ -605,7 +669,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     std::vector<int32_t> clen_prev(np, 0), clen(np, 0);
     for (int m = 0; m < n; ++m) {  // members' visible chain lengths before this call
         const int32_t* ch = c->chain_ev_h.data() + c->chain_start_h[m];
-        const int len = c->chain_start_h[m + 1] - c->chain_start_h[m];
+        const int len = c->nev[m];
         clen_prev[m] = (int32_t)(std::lower_bound(ch, ch + len, (int32_t)first) - ch);
     }
     for (int i = 0; i < S; ++i) {
@@ -614,7 +678,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         bool row0_dirty = false;
         for (int m = 0; m < n; ++m) {
             const int32_t* ch = c->chain_ev_h.data() + c->chain_start_h[m];
-            const int len = c->chain_start_h[m + 1] - c->chain_start_h[m];
+            const int len = c->nev[m];
             clen[m] = (int32_t)(std::lower_bound(ch, ch + len, (int32_t)limit) - ch);
             if (clen[m] > clen_prev[m]) {  // member touched by this sub-batch
                 if (c->front[m] < 0) {     // its root (swirld.py:195-198): lo[0][m], chain position 0
@@ -794,7 +858,6 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     if (nr == 0) return SW_OK;
     if (rounds.front() < 0 || rounds.back() >= c->R)
         return fail(c, SW_ERANGE, "find_order: round outside [0, %d) (KeyError in the reference)", c->R);
-    if (c->chains_dirty) CHK(rebuild_chains(c));
     const int rmin = rounds.front(), rmax = rounds.back();
     std::vector<int32_t> wit((size_t)(rmax - rmin + 1) * np);
     std::vector<signed char> fam((size_t)(rmax - rmin + 1) * np);
@@ -821,7 +884,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     HIPCHK(c, hipMemcpyAsync(c->d_fw_off.p, fw_off.data(), (nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_order_bounds, dim3(nr), dim3(np), 0, c->stream, (const int*)c->d_fw_ev.p, (const int*)c->d_fw_off.p,
                        (const int*)c->d_L.p, (const int*)c->d_cr.p, (const uint32_t*)c->d_stake.p, c->tot,
-                       (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, np, c->d_q.p);
+                       (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, np, c->d_q.p);
     c->ctr.kernel_launches++;
     std::vector<int32_t> q((size_t)nr * np);
     HIPCHK(c, hipMemcpyAsync(q.data(), c->d_q.p, q.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1045,6 +1108,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
     CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
+    CCHK(dgrow(c, c->d_chain_start, np, 0));
+    CCHK(dgrow(c, c->d_chain_cnt, np, 0));
     CCHK(dgrow(c, c->d_Mb, (size_t)c->MCAP * c->nw, 0));
     CCHK(fill_i32(c, c->d_evalround.p, 2 * np, -1));
     CCHK(fill_i32(c, c->d_evalpos.p, 2 * np, 0));
@@ -1077,7 +1142,7 @@ int sw_destroy(sw_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
-    dfree(c->d_chain_start); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_scat_idx); dfree(c->d_scat_val); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
@@ -1160,7 +1225,6 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         }
     }
     c->N = N0 + K;
-    c->chains_dirty = true;
     const size_t b4 = (size_t)K * sizeof(int32_t);
     HIPCHK(c, hipMemcpyAsync(c->d_cr.p + N0, c->cr.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_sp.p + N0, c->sp.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
@@ -1174,10 +1238,10 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     else HIPCHK(c, hipMemsetAsync(c->d_sig.p + (size_t)N0 * 64, 0, (size_t)K * 64, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_round.p + N0, 0xff, b4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // caller buffers may be released on return
-    // per-member chain index (CSR): part of the ingest-time layout of the hashgraph store.  Built
-    // here for bulk appends; for trickles of small appends it is rebuilt lazily by the next
-    // divide_rounds call instead (one O(N) pass either way).
-    if (K >= 4096 || K * 8 >= c->N) CHK(rebuild_chains(c));
+    // per-member chain index: part of the ingest-time layout of the hashgraph store.  Bulk appends
+    // rebuild it compactly, small appends extend the members' segments in place.
+    if (K >= 4096 || K * 8 >= c->N || c->chain_cap.empty()) CHK(rebuild_chains(c));
+    else CHK(extend_chains(c, N0, K));
     return SW_OK;
 }
 

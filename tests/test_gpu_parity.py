@@ -129,6 +129,7 @@ CASES = [
     (40, 20000, 37, 3, 0.6, 0, None),      # stale other-parents
     (64, 100000, 2, 0, 0, 0, None),        # BASELINE.json configs[1]
     (64, 30000, 38, 1, 0.01, 0, 5000),     # two cliques, incremental
+    (64, 24000, 44, 0, 0, 0, 25),          # ~1000 tiny appends: chain segments grow and relocate
     (65, 20000, 39, 0, 0, 0, None),        # first size with two mask words
     (128, 30000, 40, 0, 0, 0, None),
     (200, 30000, 41, 2, 0.1, 0.05, None),
