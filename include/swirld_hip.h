@@ -140,11 +140,12 @@ int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 /* Per-phase GPU time of the most recent divide_rounds / decide_fame call, measured with
  * hipEvents on the context's own stream (ms).  Enabled by sw_set_profiling(ctx, 1). */
 typedef struct sw_timings {
-    float can_see_ms;        /* level-synchronous can_see rows                          */
+    float can_see_ms;        /* span of the can_see stream (overlaps the round loop)     */
     float rounds_ms;         /* round-synchronous strongly-sees loop (all iterations)    */
     float tally_ms;          /* ... of which: the tally kernel (dominant kernel)         */
     int32_t tally_launches;
-    float finalize_ms;       /* round numbers, sees-masks, witness table                 */
+    float finalize_ms;       /* span of the aux stream: round numbers, sees-masks, witness   */
+                             /* rows, voter masks per sub-batch (overlaps the round loop)    */
     float fame_ms;           /* decide_fame: voter tallies + elections                   */
     float total_ms;
 } sw_timings;

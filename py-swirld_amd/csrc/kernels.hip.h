@@ -1290,7 +1290,6 @@ k_voter_masks(const int* __restrict__ wit, const int* __restrict__ L, const int*
         const u64 b = __ballot(in_s);
         if (lane == 0) out[j] = b;
     }
-    if (lane == 0) atomicAdd(&fc->voter_evals, 1ull);
 }
 
 
@@ -1336,7 +1335,6 @@ k_voter_masks_bits(const int* __restrict__ wit, const int* __restrict__ L, const
     for (int j = 0; j < NW; ++j)
         if ((w >> 1) == j) exw = (uint32_t)(ex[j] >> (32 * (w & 1)));
     if (lane < W32) out[w] = gt & exw;
-    if (lane == 0) atomicAdd(&fc->voter_evals, 1ull);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1354,8 +1352,13 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
             int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc) {
     const int r = max_c + blockIdx.x;
     const int cx = threadIdx.x;
-    if (cons[r]) return;
     const int x = wit[(size_t)r * npad + cx];
+    {   // V of SURVEY.md §8d: the reference re-evaluates every witness of rounds max_c+1..max_r as a
+        // voter in each decide_fame() call (swirld.py:238-254), decided rounds included
+        const int nw_r = __syncthreads_count(x >= 0);
+        if (cx == 0 && r > max_c) atomicAdd(&fc->voter_evals, (u64)nw_r);
+    }
+    if (cons[r]) return;
     bool active = x >= 0 && fam[(size_t)r * npad + cx] < 0;
     u64 V[NW];
 #pragma unroll

@@ -36,6 +36,8 @@ struct sw_ctx {
     std::vector<uint32_t> stake_h;
     hipStream_t stream = nullptr;
     hipStream_t stream_cs = nullptr;   // can_see sweeps run here, ahead of the round loop
+    hipStream_t stream_aux = nullptr;  // per-sub-batch finalize + voter masks run here, behind the round loop
+    FameCounters fc_seen{};            // device fame counters already added to ctr
     std::vector<hipEvent_t> cs_events;
     int pipe = 4;                       // sub-batches per divide_rounds call (pipelining depth)
     std::string err;
@@ -585,6 +587,45 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     return SW_OK;
 }
 
+
+// voter masks (decide_fame part 1) for the witnesses of rounds [r0, R) on `strm`
+template <int NW>
+int launch_voter_masks(sw_ctx* c, int r0, int R, hipStream_t strm) {
+    const int np = c->npad;
+    if (R > c->Sw_rows) {
+        int nr = c->Sw_rows ? c->Sw_rows : 256;
+        while (nr < R) nr *= 2;
+        u64* q = nullptr;
+        hipError_t e = hipMalloc((void**)&q, (size_t)nr * np * NW * sizeof(u64));
+        if (e != hipSuccess) return fail(c, SW_ENOMEM, "hipMalloc(Sw) failed: %s", hipGetErrorString(e));
+        HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+        if (c->Sw_rows && c->d_Sw.p)
+            HIPCHK(c, hipMemcpy(q, c->d_Sw.p, (size_t)c->Sw_rows * np * NW * sizeof(u64), hipMemcpyDeviceToDevice));
+        if (c->d_Sw.p) (void)hipFree(c->d_Sw.p);
+        c->d_Sw.p = q;
+        c->d_Sw.cap = (size_t)nr * np * NW;
+        c->Sw_rows = nr;
+    }
+    r0 = std::max(1, r0);
+    if (R <= r0) return SW_OK;
+    const uint32_t tot2 = 2u * c->tot;
+    const int total = (R - r0) * np;
+    if (c->unit_stake && c->tally_impl == 1)
+        hipLaunchKernelGGL(k_voter_masks_bits<NW>, dim3((total + 3) / 4), dim3(256), 0, strm,
+                           (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const uint32_t*)c->d_S.p,
+                           tot2, r0, R, np, (uint32_t*)c->d_Sw.p, c->d_fc);
+    else if (c->unit_stake)
+        hipLaunchKernelGGL((k_voter_masks<NW, true>), dim3((total + 3) / 4), dim3(256), 0, strm,
+                           (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const u64*)c->d_S.p,
+                           (const uint32_t*)c->d_stake.p, tot2, r0, R, np, c->d_Sw.p, c->d_fc);
+    else
+        hipLaunchKernelGGL((k_voter_masks<NW, false>), dim3((total + 3) / 4), dim3(256), 0, strm,
+                           (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const u64*)c->d_S.p,
+                           (const uint32_t*)c->d_stake.p, tot2, r0, R, np, c->d_Sw.p, c->d_fc);
+    c->ctr.kernel_launches++;
+    return SW_OK;
+}
+
 // height span of the events [a, b): from the ingest-time block index, edges by scanning
 void height_span(const sw_ctx* c, int64_t a, int64_t b, int* hmin, int* hmax) {
     int lo = 0x7fffffff, hi = -1;
@@ -613,8 +654,11 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     // of sub-batch i (main stream); a kernel boundary separates producer and consumer of a row
     std::vector<int64_t> cut{first};
     if (K >= 65536 && c->pipe > 1) {
-        for (int s_ = 1; s_ < c->pipe; ++s_) {
-            const int64_t bnd = ((first + K * s_ / c->pipe) >> 12) << 12;
+        // a short first sub-batch (its sweep is the only one nothing overlaps), then even parts
+        const int64_t head = K / 16;
+        for (int s_ = 0; s_ < c->pipe; ++s_) {
+            const int64_t at = s_ == 0 ? head : head + (K - head) * s_ / c->pipe;
+            const int64_t bnd = ((first + at) >> 12) << 12;
             if (bnd > cut.back() && bnd < first + K) cut.push_back(bnd);
         }
     }
@@ -663,6 +707,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     // ---- round loops, one per sub-batch, each over the events visible so far
     CHK(ensure_rounds(c, std::max(c->R, 1) + c->BATCH + 4));
     Span sp_rl = span_begin(c);
+    hipEvent_t fin_t0 = nullptr;
     float tally_ms = 0.f;
     int tally_launches = 0;
     int r_min = 0x7fffffff;
@@ -707,29 +752,37 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             for (int r = R - 1; r >= r_start; --r)
                 if (rows[(size_t)(r - r_start) * np + m] != SW_INF) { c->front[m] = std::max(c->front[m], r); break; }
         clen_prev.swap(clen);
+        // The rounds of every event below `limit` are final now (later sub-batches only add lo
+        // entries that compare greater than every existing event), so their round numbers,
+        // sees-masks, witness rows and voter masks are produced right away on a third stream,
+        // overlapping the round loop of the next sub-batch.
+        {
+            hipStream_t ax = c->stream_aux;
+            CHK(ensure_rounds(c, R + 2));
+            const int64_t a0 = cut[i], k0 = cut[i + 1] - cut[i];
+            if (i == 0 && c->profiling) { fin_t0 = next_event(c); (void)hipEventRecord(fin_t0, ax); }
+            const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, 8192);
+            hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, ax, (const int*)c->d_L.p,
+                               (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)a0, (int)k0, c->d_round.p, c->d_S.p, np);
+            const int total = (R - r_start) * np;
+            if (total > 0)
+                hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, ax,
+                                   (const int*)c->d_lo.p, R, r_start, np, c->d_wit.p);
+            c->ctr.kernel_launches += 2;
+            CHK(launch_voter_masks<NW>(c, r_start, R, ax));
+        }
     }
     span_end(c, sp_rl);
 
-    // ---- finalize: round numbers, sees-masks, witness table
-    Span sp_fin = span_begin(c);
     const int R = c->R;
-    CHK(ensure_rounds(c, R + 2));
-    {
-        const int blocks = (int)std::min<int64_t>((K + 3) / 4, 8192);
-        hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, c->stream, (const int*)c->d_L.p,
-                           (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)first, (int)K, c->d_round.p, c->d_S.p, np);
-        const int total = (R - r_min) * np;
-        if (total > 0)
-            hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                               (const int*)c->d_lo.p, R, r_min, np, c->d_wit.p);
-        c->ctr.kernel_launches += 2;
-    }
-    span_end(c, sp_fin);
+    hipEvent_t fin_t1 = nullptr;
+    if (c->profiling) { fin_t1 = next_event(c); (void)hipEventRecord(fin_t1, c->stream_aux); }
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
     span_end(c, sp_total);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream_cs));
     HIPCHK(c, hipGetLastError());
-    c->sw_dirty_from = std::min(c->sw_dirty_from, std::max(r_min, 1));
+    c->sw_dirty_from = std::max(R, 1);  // voter masks are up to date
     if (first + K == c->N) std::copy(c->head.begin(), c->head.end(), c->divided_head.begin());
     else for (int64_t e = first; e < first + K; ++e) c->divided_head[c->cr[e]] = (int32_t)e;
     c->divided = first + K;
@@ -747,7 +800,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         c->tm.rounds_ms = span_ms(sp_rl);
         c->tm.tally_ms = tally_ms;
         c->tm.tally_launches = tally_launches;
-        c->tm.finalize_ms = span_ms(sp_fin);
+        { float fm = 0.f; if (fin_t0 && fin_t1) (void)hipEventElapsedTime(&fm, fin_t0, fin_t1); c->tm.finalize_ms = fm; }  // aux stream span (overlaps)
         c->tm.total_ms = span_ms(sp_total);
     }
     return SW_OK;
@@ -760,32 +813,9 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     Span sp = span_begin(c);
     int max_c = 0;
     while (max_c < R && c->cons_h[max_c]) ++max_c;
-    // voter masks for rounds whose witness set may have changed
-    if (R > c->Sw_rows) {
-        int nr = c->Sw_rows ? c->Sw_rows : 256;
-        while (nr < R) nr *= 2;
-        CHK(dgrow(c, c->d_Sw, (size_t)nr * np * NW, (size_t)c->Sw_rows * np * NW));
-        c->Sw_rows = nr;
-    }
+    // voter masks: normally already produced by divide_rounds (per sub-batch, overlapped)
     const uint32_t tot2 = 2u * c->tot;
-    const int r0 = std::max(1, std::min(c->sw_dirty_from, R));
-    HIPCHK(c, hipMemsetAsync(c->d_fc, 0, sizeof(FameCounters), c->stream));
-    if (R > r0) {
-        const int total = (R - r0) * np;
-        if (c->unit_stake && c->tally_impl == 1)
-            hipLaunchKernelGGL(k_voter_masks_bits<NW>, dim3((total + 3) / 4), dim3(256), 0, c->stream,
-                               (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const uint32_t*)c->d_S.p,
-                               tot2, r0, R, np, (uint32_t*)c->d_Sw.p, c->d_fc);
-        else if (c->unit_stake)
-            hipLaunchKernelGGL((k_voter_masks<NW, true>), dim3((total + 3) / 4), dim3(256), 0, c->stream,
-                               (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const u64*)c->d_S.p,
-                               (const uint32_t*)c->d_stake.p, tot2, r0, R, np, c->d_Sw.p, c->d_fc);
-        else
-            hipLaunchKernelGGL((k_voter_masks<NW, false>), dim3((total + 3) / 4), dim3(256), 0, c->stream,
-                               (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const u64*)c->d_S.p,
-                               (const uint32_t*)c->d_stake.p, tot2, r0, R, np, c->d_Sw.p, c->d_fc);
-        c->ctr.kernel_launches++;
-    }
+    if (c->sw_dirty_from < R || R > c->Sw_rows) CHK(launch_voter_masks<NW>(c, std::min(c->sw_dirty_from, R), R, c->stream));
     c->sw_dirty_from = std::max(R, 1);
     HIPCHK(c, hipMemsetAsync(c->d_newc.p, 0, R, c->stream));
     if (R > max_c) {
@@ -814,8 +844,9 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
             ++cnt;
         }
     if (n_new) *n_new = cnt;
-    c->ctr.voter_evals += (int64_t)fc.voter_evals;
-    c->ctr.majority_evals += (int64_t)fc.majority_evals;
+    c->ctr.voter_evals += (int64_t)(fc.voter_evals - c->fc_seen.voter_evals);
+    c->ctr.majority_evals += (int64_t)(fc.majority_evals - c->fc_seen.majority_evals);
+    c->fc_seen = fc;
     if (c->profiling) c->tm.fame_ms = span_ms(sp);
     if (cnt > cap) return fail(c, SW_ERANGE, "new_rounds capacity %d < %d", cap, cnt);
     return SW_OK;
@@ -1083,15 +1114,18 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         if (use_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
             CHIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
             CHIP(hipStreamCreateWithPriority(&c->stream_cs, hipStreamNonBlocking, least));
+            CHIP(hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, least));
         } else {
             (void)hipGetLastError();
             CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             CHIP(hipStreamCreateWithFlags(&c->stream_cs, hipStreamNonBlocking));
+            CHIP(hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking));
         }
     }
     CHIP(hipMalloc((void**)&c->d_state, 2 * sizeof(RState)));
     CHIP(hipMemset(c->d_state, 0, 2 * sizeof(RState)));
     CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
+    CHIP(hipMemset(c->d_fc, 0, sizeof(FameCounters)));
     CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
     const int np = c->npad;
     CCHK(dgrow(c, c->d_stake, np, 0));
@@ -1159,6 +1193,7 @@ int sw_destroy(sw_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->cs_events) (void)hipEventDestroy(e);
     if (c->stream_cs) (void)hipStreamDestroy(c->stream_cs);
+    if (c->stream_aux) (void)hipStreamDestroy(c->stream_aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SW_OK;
