@@ -692,6 +692,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     int ncap = si->ncap;
     // tallies evaluated by the previous launch for this member: the slots before its first far one
     int evaluated = 0;
+    int spec_cur = -1, spec_last = -1;
     int far_wait = 0;  // the cursor candidate is FAR: decide it by inheritance below
     if (iter > 0 && un) {
         const int offered = clen - curc < K ? clen - curc : K;
@@ -699,6 +700,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         if (fnd != SW_INF && fnd < jf) {
             my_pos_next = curc + fnd;
             my_lo_next = chain_ev[cs + my_pos_next];
+            // the next round's window of this member starts here; fetch its last candidate in the
+            // same memory round trip (used for the band range if the round is entered right away)
+            spec_cur = my_pos_next;
+            spec_last = chain_ev[cs + (clen - my_pos_next < K ? clen : my_pos_next + K) - 1];
             un = 0;
         } else if (jf != SW_INF) {
             curc += jf;  // the near slots before the first far one are false
@@ -800,7 +805,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     if (done) un = 0;
     // candidates of member c in the next tally launch: chain positions [curc, curc + K)
     const int live = un ? (clen - curc < K ? clen - curc : K) : 0;
-    const int maxc = live ? chain_ev[cs + curc + live - 1] : -1;
+    const int maxc = !live ? -1 : (curc == spec_cur ? spec_last : chain_ev[cs + curc + live - 1]);
     if (c == 0) { s_cnt = 0; s_max = -1; }
     __syncthreads();
     if (live) atomicMax(&s_max, maxc);
@@ -859,9 +864,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     // a wave takes 8 consecutive band events per pass: the "is it a possible hop" test for all 8
     // in one coalesced load, then the rows of up to four valid events in flight at once
     for (int base = mask_from + wave * 8; base < mhi; base += nwaves * 8) {
+        // (masks are built for every band event: testing "can it be a hop at all" first would
+        // cost a dependent load, an unused mask costs 1 KB of row traffic)
         const int kk = base + (lane & 7);
-        const bool ok = lane < 8 && kk < mhi && kk >= s_thr[cr[kk]];  // else round[k] < r: never a hop
-        u64 vm = __ballot(ok);
+        u64 vm = __ballot(lane < 8 && kk < mhi);
         while (vm) {
             int ks[4];
 #pragma unroll
