@@ -660,6 +660,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
     __shared__ int s_res[1024];   // ... and whether it is
     __shared__ int s_cp[1024];    // chain_ev index of b's cursor candidate (-1: chain exhausted)
+    __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     const RState* si = B.st + par;
     RState* so = B.st + (1 - par);
     const bool writer = blockIdx.x == 0;
@@ -1122,6 +1123,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     constexpr int HPL = (64 * NW) / G;   // hops per lane
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
     __shared__ int s_pk[4][64 * NW];
+    __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
     const int* unres = B.unres + pb;
