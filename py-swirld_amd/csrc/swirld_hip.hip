@@ -215,6 +215,10 @@ int ensure_rounds(sw_ctx* c, int need) {
     if (need <= c->Rcap) return SW_OK;
     int nc = c->Rcap ? c->Rcap : 256;
     while (nc < need) nc *= 2;
+    // the per-round tables move: nothing may still be writing the old ones (the aux stream fills
+    // witness rows behind the round loop)
+    if (c->stream_aux) HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+    if (c->stream_cs) HIPCHK(c, hipStreamSynchronize(c->stream_cs));
     const size_t np = c->npad;
     const size_t keep = (size_t)c->Rcap * np;
     CHK(dgrow(c, c->d_lo, (size_t)nc * np, keep));
