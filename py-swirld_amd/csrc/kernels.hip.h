@@ -1153,6 +1153,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     int thr[NW], P[NW];
     u64 farm[NW];
     u64 nfar = 0;
+    uint32_t nvalid = 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         thr[j] = lo_r[j * 64 + lane];
@@ -1164,7 +1165,11 @@ k_tally_bits(LoopBufs B, int par, int K,
         pk[j * 64 + lane] = inband ? v - mlo : -1;
         farm[j] = __ballot(valid && !inband);
         nfar += __popcll(farm[j]);
+        nvalid += __popcll(__ballot(valid));
     }
+    // necessary condition: a member is strongly seen only through more than 2T/3 (unit-stake)
+    // hops, so with fewer valid hops no column can pass — skip the gathers altogether
+    if (3u * nvalid <= tot2) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int w = lane % W32, g = lane / W32;
