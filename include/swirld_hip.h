@@ -151,6 +151,10 @@ typedef struct sw_timings {
 } sw_timings;
 int sw_set_profiling(sw_ctx* ctx, int enable);
 int sw_get_timings(sw_ctx* ctx, sw_timings* out);
+/* Diagnostics: with SW_DEBUG_CLOCKS=1 in the environment at sw_create, the two round-loop kernels
+ * stamp their phases (100 MHz clock) per iteration; copies up to cap_words of the
+ * [4096 iterations][32] table of the most recent run.  profiles/loop_phases.py reads it. */
+int sw_debug_clocks(sw_ctx* ctx, unsigned long long* out, int64_t cap_words);
 
 /* Measurement utility (no reference counterpart): forget all voting state (rounds,
  * witnesses, fame, consensus, order) as if divide_rounds had never been called; the

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Where the time of one round-loop iteration goes: phase stamps written by k_resolve_band and
+k_tally_bits themselves (SW_DEBUG_CLOCKS=1, 100 MHz clock, each stamp after a full s_waitcnt).
+Usage: SW_DEBUG_CLOCKS=1 SW_PIPE=1 python profiles/loop_phases.py [members events]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SW_DEBUG_CLOCKS", "1")
+pkg = importlib.import_module("py-swirld_amd")
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+stream = pkg.synth_hashgraph(n, N, 3)
+h = pkg.Hashgraph(n)
+h.reserve(N)
+h.append_events(*stream)
+for _ in range(2):
+    h.divide_rounds(0, N)
+    h.decide_fame()
+    h.rewind()
+h.divide_rounds(0, N)
+t = h.debug_clocks().astype(np.int64)
+live = (t[:, 0] > 0) & (t[:, 6] > 0)
+live[:-1] &= t[1:, 0] > 0
+idx = np.nonzero(live)[0][1:-1]
+print("%d members, %d events: %d stamped iterations" % (n, N, len(idx)))
+
+
+def q(name, d):
+    d = d / 100.0  # 100 MHz -> us
+    print("  %-52s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f us" % (name, d.mean(), *np.percentile(d, [10, 50, 90])))
+
+
+A, T, Tl = 0, 16, 24
+q("iteration period (resolve entry -> next resolve entry)", t[idx + 1, A] - t[idx, A])
+print(" k_resolve_band, block 1 (a block that does not publish the state):")
+order = [0, 1, 2, 3, 8, 10, 4, 12, 13, 14, 5, 6]
+names = ["first loads back", "cursors advanced (chain_ev round trip)", "inheritance, count(unresolved)",
+         "round committed", "count(active), count(unresolved), min threshold", "next round entered",
+         "last candidate known", "max(last candidate), sum(evaluated)", "band range", "(state stores: writer only)",
+         "band masks built (this block's share)"]
+for a, b, nm in zip(order[:-1], order[1:], names):
+    ok = (t[idx, a] > 0) & (t[idx, b] > 0)
+    q("-> " + nm, t[idx[ok], b] - t[idx[ok], a])
+q("end - entry", t[idx, 6] - t[idx, 0])
+print("  band events per iteration: mean %.0f" % t[idx, A + 7].mean())
+kend = t[idx, A + 6]
+for name, b in (("member 0, slot K/2", T), ("last member, slot K/2", Tl)):
+    ok = (t[idx, b] > 0) & (t[idx, b + 1] > 0)
+    i1 = idx[ok]
+    print(" k_tally_bits, wave of %s (%d iterations reached it):" % (name, len(i1)))
+    if not len(i1):
+        continue
+    q("resolve end (stamped blocks) -> entry", t[i1, b] - kend[ok])
+    q("entry -> first loads back", t[i1, b + 1] - t[i1, b])
+    for k, lab in ((2, "-> candidate + self-parent ids"), (3, "-> can_see row + other-parent"),
+                   (4, "-> hop masks gathered + counted"), (5, "-> compared, result published")):
+        okk = (t[i1, b + k] > 0) & (t[i1, b + k - 1] > 0)
+        if okk.any():
+            q(lab + " (%d)" % okk.sum(), t[i1[okk], b + k] - t[i1[okk], b + k - 1])
+    okk = t[i1, b + 5] > 0
+    if okk.any():
+        q("end - entry", t[i1[okk], b + 5] - t[i1[okk], b])
+        q("end -> next resolve entry", t[i1[okk] + 1, A] - t[i1[okk], b + 5])

@@ -58,6 +58,7 @@ SIGNATURES = {
     "sw_get_counters": (C.c_int, [_P, C.POINTER(Counters)]),
     "sw_set_profiling": (C.c_int, [_P, C.c_int]),
     "sw_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),
+    "sw_debug_clocks": (C.c_int, [_P, _P, C.c_int64]),
     "sw_rewind": (C.c_int, [_P]),
     "sw_synchronize": (C.c_int, [_P]),
     "sw_synth_hashgraph": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_double,

@@ -640,7 +640,45 @@ struct LoopBufs {
     int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
     int* farslot;     // [2][npad] smallest candidate slot that was FAR (not tallied; INF: none)
     int* force;       // [2][npad] tally the member's cursor candidate even though it is far
+    u64* dbg;         // diagnostics (SW_DEBUG_CLOCKS=1): [iteration][32] wall-clock stamps, else null
 };
+
+// Kernel arguments are fetched lazily by the compiler (an s_load right before the first use, one
+// per 64-byte line of the kernarg segment), and every such fetch is a dependent scalar-cache miss
+// in the middle of a latency-bound kernel.  Pinning makes all of them arrive with the first one.
+__device__ __forceinline__ void pin_arg(const void* p) { asm volatile("" ::"s"((unsigned long long)p)); }
+__device__ __forceinline__ void pin_arg(int v) { asm volatile("" ::"s"(v)); }
+__device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v)); }
+
+// phase stamps of the round-loop kernels (100 MHz constant clock); only with SW_DEBUG_CLOCKS=1.
+// The wait makes the stamp mean "everything issued so far has completed".
+#define SW_DBG_MAX_ITERS 4096
+#define SW_STAMP(cond, it, slot)                                                          \
+    do {                                                                                  \
+        if (B.dbg && (cond) && (it) < SW_DBG_MAX_ITERS) {                                 \
+            __builtin_amdgcn_s_waitcnt(0);                                                \
+            B.dbg[(size_t)(it) * 32 + (slot)] = wall_clock64();                           \
+        }                                                                                 \
+    } while (0)
+
+// Wave and workgroup reductions for the resolve step.  LDS atomics on one address with a
+// different value per lane are expanded by the compiler into a 64-trip scalar loop (~2 us on the
+// critical path of every iteration): butterflies + one LDS slot per wave + ONE barrier instead.
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
 // Step 1 (replicated, one thread per member): consume the tally results, advance the
 // per-member cursors, commit lo[r+1] when every member is resolved, enter the next round that
@@ -653,44 +691,57 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
                const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb) {
-    __shared__ int s_min;
-    __shared__ int s_max;
-    __shared__ int s_cnt;
+    __shared__ int s_red[2][4][16];  // [parity][quantity][wave]: per-wave partial results
     __shared__ int s_thr[1024];
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
     __shared__ int s_res[1024];   // ... and whether it is
     __shared__ int s_cp[1024];    // chain_ev index of b's cursor candidate (-1: chain exhausted)
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
+    pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.lo_next); pin_arg(B.pos_next);
+    pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
+    pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
+    pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
+    pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
     const RState* si = B.st + par;
     RState* so = B.st + (1 - par);
     const bool writer = blockIdx.x == 0;
     const int c = threadIdx.x;
     const size_t in = (size_t)par * npad, out = (size_t)(1 - par) * npad;
-    if (si->done) {
-        if (writer && c == 0) *so = *si;
-        return;
-    }
     const bool member = c < npad;
+    // First memory round trip: the loop state and every per-member value whose address does not
+    // depend on it, issued together BEFORE the first branch (a load behind an early return cannot
+    // be hoisted by the compiler and would cost a dependent round trip of its own).
+    const int s_done = si->done;
     int r = si->r;
     const int iter = si->iter;
-    // independent loads first (one memory round trip instead of a dependent chain)
+    const int N = si->N;
+    const int s_mlo = si->mlo, s_mhi = si->mhi, s_ncap = si->ncap;
     const int cs = member ? chain_start[c] : 0;
     const int clen = member ? chain_len[c] : 0;  // events of member c visible to this run
-    const int N = si->N;
     int un = member ? B.unres[in + c] : 0;
     int curc = member ? B.cur[in + c] : 0;
     const int fnd = member ? B.found[in + c] : SW_INF;
     const int jf = member ? B.farslot[in + c] : SW_INF;
     int frc = member ? B.force[in + c] : 0;
+    int evr_now = member ? B.evalround[in + c] : -1, evp_now = member ? B.evalpos[in + c] : 0;
+    const int in_lo_next = member ? B.lo_next[in + c] : SW_INF;
+    const int in_pos_next = member ? B.pos_next[in + c] : 0;
+    int thr = member ? B.lo_r[in + c] : SW_INF;
+    const bool stamp = c == 0 && blockIdx.x == 1;  // a block that does not publish the state
+    const int sb = 0;
+    if (B.dbg && stamp && !s_done && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb] = wall_clock64();
+    SW_STAMP(stamp && !s_done, iter, sb + 1);
+    if (s_done) {
+        if (writer && c == 0) *so = *si;
+        return;
+    }
     const int lo_r1 = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
     const int lo_r2 = (member && r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
     const int lopos_r1 = (member && r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
-    int evr_now = member ? B.evalround[in + c] : -1, evp_now = member ? B.evalpos[in + c] : 0;
-    int my_lo_next = (member && iter > 0) ? B.lo_next[in + c] : SW_INF;
-    int my_pos_next = (member && iter > 0) ? B.pos_next[in + c] : 0;
-    int thr = member ? B.lo_r[in + c] : SW_INF;
-    int mlo = si->mlo, mhi = si->mhi;
-    int ncap = si->ncap;
+    int my_lo_next = iter > 0 ? in_lo_next : SW_INF;
+    int my_pos_next = iter > 0 ? in_pos_next : 0;
+    int mlo = s_mlo, mhi = s_mhi;
+    int ncap = s_ncap;
     // tallies evaluated by the previous launch for this member: the slots before its first far one
     int evaluated = 0;
     int spec_cur = -1, spec_last = -1;
@@ -724,6 +775,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     // lies before that creator's cursor; otherwise c waits for the next iteration.  When both
     // parents have round <= r the candidate needs a real tally: the band cap is doubled.
     int grow = 0;
+    SW_STAMP(stamp, iter, sb + 2);
     if (iter > 0) {
         if (member) {
             // a member is "resolved for round r" unless it is still searching
@@ -747,9 +799,18 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
                 if (ncap >= MCAP) frc = 1;  // cap exhausted: tally it with on-the-fly hop masks
             }
         }
-        if (__syncthreads_or(grow) && ncap < MCAP) ncap = ncap * 2 < MCAP ? ncap * 2 : MCAP;
     }
-    int nun = __syncthreads_count(un);
+    const int rl = c & 63, rw = c >> 6, nwv = blockDim.x >> 6;
+    int nun = 0;
+    {   // count(un) and any(grow) with one barrier
+        const u64 bu = __ballot(un != 0), bg = __ballot(grow != 0);
+        if (rl == 0) { s_red[0][0][rw] = __popcll(bu); s_red[0][1][rw] = bg != 0; }
+        __syncthreads();
+        int anyg = 0;
+        for (int w = 0; w < nwv; ++w) { nun += s_red[0][0][w]; anyg |= s_red[0][1][w]; }
+        if (anyg && ncap < MCAP) ncap = ncap * 2 < MCAP ? ncap * 2 : MCAP;
+    }
+    SW_STAMP(stamp, iter, sb + 3);
     int need_mask = 0, done = 0, err = 0, max_round = 0;
     if (nun == 0) {
         int lr, nx, start;
@@ -772,6 +833,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
             start = (member && r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
             nx = lo_r1;
         }
+        SW_STAMP(stamp, iter, 8);
+        int lp = 1;  // s_red[0] was used by the count above
         for (;;) {  // enter the next round that has unresolved members
             if (r + 1 >= Rcap) { err = 1; done = 1; break; }
             const int act = lr != SW_INF;
@@ -781,15 +844,28 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
                 curc = start;
                 un = start < clen;
             }
-            const int nact = __syncthreads_count(act);
+            // count(act), count(un), min(lr over the active members) with one barrier; the LDS
+            // slots alternate between passes of this loop (a wave is at most one barrier ahead)
+            int nact = 0, minlr = SW_INF;
+            {
+                const u64 ba = __ballot(act != 0), bu = __ballot(un != 0);
+                const int wm = wave_min_i32(act ? lr : SW_INF);
+                if (rl == 0) { s_red[lp][0][rw] = __popcll(ba); s_red[lp][1][rw] = __popcll(bu); s_red[lp][2][rw] = wm; }
+                __syncthreads();
+                nun = 0;
+                for (int w = 0; w < nwv; ++w) {
+                    nact += s_red[lp][0][w];
+                    nun += s_red[lp][1][w];
+                    const int m = s_red[lp][2][w];
+                    minlr = m < minlr ? m : minlr;
+                }
+                lp ^= 1;
+            }
+            SW_STAMP(stamp, iter, 10);
             if (nact == 0) { done = 1; max_round = r - 1; break; }
-            nun = __syncthreads_count(un);
             if (nun > 0) {
-                if (c == 0) s_min = SW_INF;
-                __syncthreads();
-                if (act) atomicMin(&s_min, lr);
-                __syncthreads();
-                mlo = s_min;
+                SW_STAMP(stamp, iter, 11);
+                mlo = minlr;
                 thr = lr;
                 my_lo_next = SW_INF;
                 need_mask = 1;
@@ -804,15 +880,26 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         }
     }
     if (done) un = 0;
+    SW_STAMP(stamp, iter, sb + 4);
     // candidates of member c in the next tally launch: chain positions [curc, curc + K)
     const int live = un ? (clen - curc < K ? clen - curc : K) : 0;
     const int maxc = !live ? -1 : (curc == spec_cur ? spec_last : chain_ev[cs + curc + live - 1]);
-    if (c == 0) { s_cnt = 0; s_max = -1; }
-    __syncthreads();
-    if (live) atomicMax(&s_max, maxc);
-    if (evaluated) atomicAdd(&s_cnt, evaluated);
-    if (member) s_thr[c] = thr;
-    __syncthreads();
+    SW_STAMP(stamp, iter, 12);
+    int s_max = -1, s_cnt = 0;
+    {   // max(last candidate), sum(evaluated) and the thresholds for the band, one barrier
+        // (the [.][3] slots are written only here, once per launch)
+        const int wmx = wave_max_i32(live ? maxc : -1);
+        const int wsm = wave_sum_i32(evaluated);
+        if (rl == 0) { s_red[0][3][rw] = wmx; s_red[1][3][rw] = wsm; }
+        if (member) s_thr[c] = thr;
+        __syncthreads();
+        for (int w = 0; w < nwv; ++w) {
+            const int m = s_red[0][3][w];
+            s_max = m > s_max ? m : s_max;
+            s_cnt += s_red[1][3][w];
+        }
+    }
+    SW_STAMP(stamp, iter, 13);
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
     // (hops beyond the cap are rebuilt from their rows by the tally kernel)
     int mask_from = mlo;
@@ -828,6 +915,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
             need_mask = 1;
         }
     }
+    SW_STAMP(stamp, iter, 14);
     if (writer) {
         if (member) {
             B.unres[out + c] = un;
@@ -854,11 +942,17 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         }
     }
     // ---- band masks
+    SW_STAMP(stamp, iter, sb + 5);
+    if (B.dbg && stamp && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb + 7] = (u64)(need_mask ? mhi - mask_from : 0);
     if (done || !need_mask) return;
     const int lane = lane_id();
     const int wpb = blockDim.x >> 6;
-    const int wave = blockIdx.x * wpb + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * wpb;
+    // the writer block finishes later than the others (it publishes the state): it takes no
+    // share of the band, so that the kernel ends with the band and not with its stores
+    const int skipw = gridDim.x > 1 ? 1 : 0;
+    if (skipw && writer) return;
+    const int wave = (blockIdx.x - skipw) * wpb + (threadIdx.x >> 6);
+    const int nwaves = (gridDim.x - skipw) * wpb;
     int t_[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) t_[j] = s_thr[j * 64 + lane];
@@ -893,6 +987,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
                 }
         }
     }
+    SW_STAMP(stamp, iter, sb + 6);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1124,40 +1219,55 @@ k_tally_bits(LoopBufs B, int par, int K,
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
     __shared__ int s_pk[4][64 * NW];
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
+    pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.found); pin_arg(B.farslot);
+    pin_arg(B.force); pin_arg(B.dbg); pin_arg(par); pin_arg(K); pin_arg(chain_start); pin_arg(chain_len);
+    pin_arg(chain_ev); pin_arg(L); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
-    const int* unres = B.unres + pb;
-    const int* cur = B.cur + pb;
-    const int* lo_r = B.lo_r + pb;
     int* found = B.found + pb;
-    if (st->done) return;
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
     const int wv = blockIdx.x * 4 + wib;
     const int cm = wv / K, cj = wv - cm * K;  // member, candidate slot
-    if (!unres[cm]) return;
-    const int ccs = chain_start[cm];
-    const int cp = cur[cm] + cj;
-    if (cp >= chain_len[cm]) return;
-    const int e = chain_ev[ccs + cp];
-    const int mlo = st->mlo, mhi = st->mhi;
-    int* pk = s_pk[wib];
-    const int ce = cr[e], spe = sp[e];
-    {   // FAR candidate (a parent beyond the band): decided by inheritance in k_resolve_band
-        const int ope = op[e];
-        if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && B.force[pb + cm])) {
-            if (lane == 0) atomicMin(&B.farslot[pb + cm], cj);
-            return;
-        }
-    }
+    // Round trip 1: everything addressed by the launch parameters alone, issued before the first
+    // branch.  Round trip 2: the candidate and its self-parent (the previous event of the same
+    // chain: divide_rounds refuses forks, and creator(e) = cm by construction).  Round trip 3:
+    // its can_see row and other-parent.  Round trip 4: the gathered hop masks.
+    const int s_done = st->done, mlo = st->mlo, mhi = st->mhi;
+    const int un = B.unres[pb + cm], cu = B.cur[pb + cm], frc = B.force[pb + cm];
+    const int ccs = chain_start[cm], ccl = chain_len[cm];
     int thr[NW], P[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
+    // stamped waves: candidate slot K/2 of the first and of the last member
+    const bool stamp = B.dbg && lane == 0 && cj == (K >> 1) && (cm == 0 || cm == (int)(gridDim.x * 4 / K) - 1);
+    const int sb = cm == 0 ? 16 : 24;
+    const int it_ = stamp ? st->iter - 1 : 0;
+    if (stamp && !s_done && it_ < SW_DBG_MAX_ITERS) B.dbg[(size_t)it_ * 32 + sb] = wall_clock64();
+    SW_STAMP(stamp && !s_done, it_, sb + 1);
+    if (s_done || !un) return;
+    const int cp = cu + cj;
+    if (cp >= ccl) return;
+    const int e = chain_ev[ccs + cp];
+    const int spe = cp > 0 ? chain_ev[ccs + cp - 1] : -1;
+    const int ce = cm;
+    int* pk = s_pk[wib];
+    SW_STAMP(stamp, it_, sb + 2);
+    const int ope = op[e];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) P[j] = L[(size_t)e * npad + j * 64 + lane];
+    SW_STAMP(stamp, it_, sb + 3);
+    // FAR candidate (a parent beyond the band): decided by inheritance in k_resolve_band
+    if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && frc)) {
+        if (lane == 0) atomicMin(&B.farslot[pb + cm], cj);
+        return;
+    }
     u64 farm[NW];
     u64 nfar = 0;
     uint32_t nvalid = 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-        thr[j] = lo_r[j * 64 + lane];
-        int v = L[(size_t)e * npad + j * 64 + lane];
+        int v = P[j];
         if (j * 64 + lane == ce) v = spe;  // the row BEFORE the self overwrite (Q4)
         P[j] = v;
         const bool valid = v >= thr[j];
@@ -1175,6 +1285,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     const int w = lane % W32, g = lane / W32;
     uint32_t b[PLT];
     bits_accumulate<NW>(pk, Mb32, b, lane);
+    SW_STAMP(stamp, it_, sb + 4);
     if (nfar) {  // rare: hops outside the band, masks built from their rows on the fly
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
@@ -1202,6 +1313,7 @@ k_tally_bits(LoopBufs B, int par, int K,
         if (3u * cnt > tot2) atomicMin(&found[cm], cj);  // count of members vs the STAKE threshold (Q2)
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
+    SW_STAMP(stamp, it_, sb + 5);
 }
 
 // ---------------------------------------------------------------------------------

@@ -81,6 +81,7 @@ struct sw_ctx {
     DBuf<unsigned char> d_cons, d_newc;
     DBuf<u64> d_Sw;
     int Sw_rows = 0;
+    unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force;
     DBuf<u64> d_Mb;
     RState* d_state = nullptr;
@@ -449,6 +450,7 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.found = c->d_found.p;
     B.farslot = c->d_farslot.p;
     B.force = c->d_force.p;
+    B.dbg = c->d_dbg;
     return B;
 }
 
@@ -1093,6 +1095,10 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
+    if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
+        if (hipMalloc(&c->d_dbg, (size_t)SW_DBG_MAX_ITERS * 32 * 8) != hipSuccess) c->d_dbg = nullptr;
+        else (void)hipMemset(c->d_dbg, 0, (size_t)SW_DBG_MAX_ITERS * 32 * 8);
+    }
     c->nev.assign(n_members, 0);
     {
         // LDS ring depth of the can_see kernel: largest power of two <= 8 that fits 144 KiB
@@ -1184,6 +1190,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
+    if (c->d_dbg) (void)hipFree(c->d_dbg);
     dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_Mb);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
@@ -1508,6 +1515,15 @@ int sw_get_counters(sw_ctx* c, sw_counters* out) {
 int sw_set_profiling(sw_ctx* c, int enable) {
     if (!c) return SW_EINVAL;
     c->profiling = enable != 0;
+    return SW_OK;
+}
+
+int sw_debug_clocks(sw_ctx* c, unsigned long long* out, int64_t cap_words) {
+    if (!c || !out) return SW_EINVAL;
+    if (!c->d_dbg) return fail(c, SW_EINVAL, "sw_debug_clocks: the context was not created with SW_DEBUG_CLOCKS=1");
+    const int64_t nw = std::min<int64_t>(cap_words, (int64_t)SW_DBG_MAX_ITERS * 32);
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->d_dbg, (size_t)nw * 8, hipMemcpyDeviceToHost));
     return SW_OK;
 }
 

@@ -156,6 +156,12 @@ class Hashgraph:
         return {k: (int(getattr(t, k)) if k == "tally_launches" else float(getattr(t, k)))
                 for k, _ in Timings._fields_}
 
+    def debug_clocks(self):
+        """[4096][32] uint64 phase stamps of the round-loop kernels (needs SW_DEBUG_CLOCKS=1 at creation)."""
+        out = np.zeros((4096, 32), np.uint64)
+        self._chk(self._L.sw_debug_clocks(self._h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
     def rewind(self):
         """Forget all voting state; the ingested events stay resident (bench utility)."""
         self._chk(self._L.sw_rewind(self._h))
