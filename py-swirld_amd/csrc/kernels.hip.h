@@ -1177,6 +1177,108 @@ __device__ __forceinline__ void bits_accumulate(const int* pk, const uint32_t* _
     }
 }
 
+// The same for the round-loop tally, with the dependent chain taken out of the gathers: `pk` holds
+// table rows (row 0 = all-zero = "not a hop": no branch around the load), laid out so that the
+// hops of lane group g are contiguous (pk[g * PKS + i] = hop g + G*i; wide LDS reads, issued ahead
+// of the loads), and the offsets are 32-bit (scalar base + vector offset addressing).
+// Only the planes a per-lane count can reach (<= HPL) are touched.
+template <int PLT, int TOP>
+__device__ __forceinline__ void ripple_add_to(uint32_t (&b)[PLT], uint32_t x, const int from) {
+#pragma unroll
+    for (int p = 0; p < TOP; ++p) {
+        if (p >= from) {
+            const uint32_t t = b[p] & x;
+            b[p] ^= x;
+            x = t;
+        }
+    }
+}
+
+template <int NW>
+struct BitsGeom {
+    static constexpr int W32 = 2 * NW, G = 64 / W32, HPL = (64 * NW) / G, PLT = ilog2_c(64 * NW) + 1;
+    static constexpr int PKS = HPL + 4;              // padded row of pk (keeps 16-byte alignment)
+    static constexpr int PA = ilog2_c(HPL) + 1;      // planes of a per-lane count
+    static constexpr int PK_INTS = G * PKS;
+    __device__ static __forceinline__ int slot(int h) { return (h % G) * PKS + h / G; }
+};
+
+template <int NW>
+__device__ __forceinline__ void bits_accumulate_z(const int* pk, const uint32_t* __restrict__ table32,
+                                                  uint32_t (&b)[ilog2_c(64 * NW) + 1], const int lane) {
+    using Gm = BitsGeom<NW>;
+    constexpr int W32 = Gm::W32, HPL = Gm::HPL, PLT = Gm::PLT, PA = Gm::PA;
+    const uint32_t w = lane % W32;
+    const int g = lane / W32;
+    const int* row = pk + g * Gm::PKS;
+    // uniform base + 32-bit byte offset (the table is at most (MCAP + 1) * 8 * NW bytes << 4 GB)
+    const char* tb = reinterpret_cast<const char*>(table32);
+    const uint32_t wb = w * 4u;
+    auto ld = [&](int k) -> uint32_t {
+        return *reinterpret_cast<const uint32_t*>(tb + ((uint32_t)k * (uint32_t)(W32 * 4) + wb));
+    };
+#pragma unroll
+    for (int p = 0; p < PLT; ++p) b[p] = 0;
+    if constexpr (HPL >= 8) {
+#pragma unroll 4
+        for (int i0 = 0; i0 < HPL; i0 += 8) {
+            const int4 k0 = *reinterpret_cast<const int4*>(row + i0);
+            const int4 k1 = *reinterpret_cast<const int4*>(row + i0 + 4);
+            uint32_t x[8];
+            x[0] = ld(k0.x); x[1] = ld(k0.y); x[2] = ld(k0.z); x[3] = ld(k0.w);
+            x[4] = ld(k1.x); x[5] = ld(k1.y); x[6] = ld(k1.z); x[7] = ld(k1.w);
+            uint32_t twoA, twoB, twoC, twoD, fourA, fourB, eight;
+            csa(twoA, b[0], b[0], x[0], x[1]);
+            csa(twoB, b[0], b[0], x[2], x[3]);
+            csa(fourA, b[1], b[1], twoA, twoB);
+            csa(twoC, b[0], b[0], x[4], x[5]);
+            csa(twoD, b[0], b[0], x[6], x[7]);
+            csa(fourB, b[1], b[1], twoC, twoD);
+            csa(eight, b[2], b[2], fourA, fourB);
+            ripple_add_to<PLT, PA>(b, eight, 3);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+            const uint32_t x = ld(row[i]);
+            ripple_add_to<PLT, PA>(b, x, 0);
+        }
+    }
+}
+
+// cross-lane part for bits_accumulate_z: level k adds two counts of PA + k planes
+template <int NW>
+__device__ __forceinline__ uint32_t bits_finish_z(uint32_t (&b)[ilog2_c(64 * NW) + 1], const uint32_t t23) {
+    using Gm = BitsGeom<NW>;
+    constexpr int W32 = Gm::W32, PLT = Gm::PLT;
+    int top = Gm::PA;
+#pragma unroll
+    for (int off = W32; off < 64; off <<= 1) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int p = 0; p < PLT; ++p) {
+            if (p < top) {
+                const uint32_t y = (uint32_t)__shfl_xor((int)b[p], off);
+                const uint32_t u = b[p] ^ y;
+                const uint32_t nc = (b[p] & y) | (u & carry);
+                b[p] = u ^ carry;
+                carry = nc;
+            }
+        }
+        if (top < PLT) b[top] = carry;
+        ++top;
+    }
+    uint32_t gt = 0, eq = 0xffffffffu;  // most significant plane first
+#pragma unroll
+    for (int p = PLT - 1; p >= 0; --p) {
+        const uint32_t tb = ((t23 >> p) & 1u) ? 0xffffffffu : 0u;
+        gt |= eq & b[p] & ~tb;
+        eq &= ~(b[p] ^ tb);
+    }
+    if ((t23 >> PLT) != 0) gt = 0;  // threshold beyond any possible count
+    return gt;
+}
+
 // part 2: add the G hop groups across lanes (bit-sliced full adders) and compare every
 // member's count with t23 = floor(2T/3); returns, in every lane (g, w), the 32-member word w
 // of "hits > 2T/3".
@@ -1207,7 +1309,7 @@ __device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) +
 }
 
 template <int NW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 4 ? 8 : 2, 8)))
 k_tally_bits(LoopBufs B, int par, int K,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
              const int* __restrict__ chain_ev,
@@ -1217,7 +1319,8 @@ k_tally_bits(LoopBufs B, int par, int K,
     constexpr int G = 64 / W32;          // hop groups
     constexpr int HPL = (64 * NW) / G;   // hops per lane
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
-    __shared__ int s_pk[4][64 * NW];
+    using Gm = BitsGeom<NW>;
+    __shared__ __attribute__((aligned(16))) int s_pk[4][Gm::PK_INTS];
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.found); pin_arg(B.farslot);
     pin_arg(B.force); pin_arg(B.dbg); pin_arg(par); pin_arg(K); pin_arg(chain_start); pin_arg(chain_len);
@@ -1272,7 +1375,7 @@ k_tally_bits(LoopBufs B, int par, int K,
         P[j] = v;
         const bool valid = v >= thr[j];
         const bool inband = valid && v < mhi;
-        pk[j * 64 + lane] = inband ? v - mlo : -1;
+        pk[Gm::slot(j * 64 + lane)] = inband ? v - mlo + 1 : 0;  // row 0 of the table is all-zero
         farm[j] = __ballot(valid && !inband);
         nfar += __popcll(farm[j]);
         nvalid += __popcll(__ballot(valid));
@@ -1284,7 +1387,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     __builtin_amdgcn_wave_barrier();
     const int w = lane % W32, g = lane / W32;
     uint32_t b[PLT];
-    bits_accumulate<NW>(pk, Mb32, b, lane);
+    bits_accumulate_z<NW>(pk, Mb32, b, lane);
     SW_STAMP(stamp, it_, sb + 4);
     if (nfar) {  // rare: hops outside the band, masks built from their rows on the fly
 #pragma unroll
@@ -1305,7 +1408,7 @@ k_tally_bits(LoopBufs B, int par, int K,
             }
         }
     }
-    const uint32_t gt = bits_finish<NW>(b, tot2 / 3u);
+    const uint32_t gt = bits_finish_z<NW>(b, tot2 / 3u);
     uint32_t cnt = (g == 0) ? __popc(gt) : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);

@@ -468,7 +468,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans) {
     hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p);
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW);
     Span s{};
     if (tally_spans) s = span_begin(c);
     if (c->unit_stake && c->tally_impl == 1)
@@ -480,12 +480,12 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans) {
         hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                           (const u64*)c->d_Mb.p, (const uint32_t*)c->d_stake.p, tot2, np);
+                           (const u64*)(c->d_Mb.p + NW), (const uint32_t*)c->d_stake.p, tot2, np);
     else
         hipLaunchKernelGGL((k_tally_candidates<NW, false>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                           (const u64*)c->d_Mb.p, (const uint32_t*)c->d_stake.p, tot2, np);
+                           (const u64*)(c->d_Mb.p + NW), (const uint32_t*)c->d_stake.p, tot2, np);
     if (tally_spans) { span_end(c, s); tally_spans->push_back(s); }
     c->ctr.kernel_launches += 2;
 }
@@ -1154,7 +1154,10 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_chain_start, np, 0));
     CCHK(dgrow(c, c->d_chain_cnt, np, 0));
-    CCHK(dgrow(c, c->d_Mb, (size_t)c->MCAP * c->nw, 0));
+    // band masks; row 0 stays all-zero (the bit-sliced tally points "not a hop" at it), the band
+    // proper starts at row 1
+    CCHK(dgrow(c, c->d_Mb, ((size_t)c->MCAP + 1) * c->nw, 0));
+    if (hipMemset(c->d_Mb.p, 0, (size_t)c->nw * sizeof(u64)) != hipSuccess) { sw_destroy(c); return SW_EIO; }
     CCHK(fill_i32(c, c->d_evalround.p, 2 * np, -1));
     CCHK(fill_i32(c, c->d_evalpos.p, 2 * np, 0));
     CCHK(fill_i32(c, c->d_lo_r.p, 2 * np, SW_INF));
