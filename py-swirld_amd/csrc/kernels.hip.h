@@ -963,21 +963,22 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         // cost a dependent load, an unused mask costs 1 KB of row traffic)
         const int kk = base + (lane & 7);
         u64 vm = __ballot(lane < 8 && kk < mhi);
+        constexpr int RIF = NW <= 4 ? 8 : 4;  // rows in flight per wave (one memory round trip per pass)
         while (vm) {
-            int ks[4];
+            int ks[RIF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RIF; ++u) {
                 ks[u] = -1;
                 if (vm) { ks[u] = base + __ffsll((long long)vm) - 1; vm &= vm - 1; }
             }
-            int v[4][NW];
+            int v[RIF][NW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < RIF; ++u)
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
                     v[u][j] = ks[u] >= 0 ? L[(size_t)ks[u] * npad + j * 64 + lane] : -1;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < RIF; ++u)
                 if (ks[u] >= 0) {
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {

@@ -92,7 +92,8 @@ struct sw_ctx {
     int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
 
     // tuning
-    int K = 32;        // candidates per member per tally launch
+    int K = 28;        // candidates per member per tally launch: 7 waves per SIMD (the 8th slot is
+                       // taken by the concurrent can_see sweep; 29+ costs a second wave generation)
     int MCAP = 0;      // largest band (events) the mask table can hold
     int NEARCAP = 0;   // band cap at round entry (doubles up to MCAP when a far candidate needs a tally)
     int BATCH = 24;    // loop iterations between host checks
