@@ -1588,6 +1588,12 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
         if (cx == 0 && r > max_c) atomicAdd(&fc->voter_evals, (u64)nw_r);
     }
     if (cons[r]) return;
+    // the voters of a round are staged through LDS 64 at a time (64 voters x NW words = one word
+    // per thread, one coalesced load): reading them straight from memory is a chain of dependent
+    // uniform loads, ~0.3 us per voter
+    __shared__ int s_wv[64];
+    __shared__ u64 s_m[64 * NW];
+    __shared__ u64 s_p2[16];
     bool active = x >= 0 && fam[(size_t)r * npad + cx] < 0;
     u64 V[NW];
 #pragma unroll
@@ -1604,13 +1610,16 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
         const bool coin_round = (d % coin_period) == 0;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
+            __syncthreads();  // the previous chunk has been consumed
+            s_m[cx] = sw_row[(size_t)j * 64 * NW + cx];
+            if (cx < 64) s_wv[cx] = wv_row[j * 64 + cx];
+            __syncthreads();
             u64 acc = 0;
             for (int ci = 0; ci < 64; ++ci) {
-                const int c = j * 64 + ci;
-                const int wv = wv_row[c];  // uniform
+                const int wv = s_wv[ci];  // uniform
                 if (wv < 0) continue;
                 ++nvoters;
-                const u64* m = sw_row + (size_t)c * NW;
+                const u64* m = s_m + ci * NW;
                 int bitv;
                 if (d == 1) {
                     bitv = (int)((m[cx >> 6] >> (cx & 63)) & 1ull);  // x in s (swirld.py:258)
@@ -1676,7 +1685,18 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
         newc[r] = 1;
         cons[r] = 1;
     }
-    if (p2) atomicAdd(&fc->majority_evals, p2);
+    {   // one atomic per workgroup
+        u64 t = p2;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += (u64)__shfl_xor((long long)t, off);
+        if ((cx & 63) == 0) s_p2[cx >> 6] = t;
+        __syncthreads();
+        if (cx == 0) {
+            u64 tot = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_p2[w];
+            if (tot) atomicAdd(&fc->majority_evals, tot);
+        }
+    }
 }
 
 

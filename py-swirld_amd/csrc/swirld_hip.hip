@@ -660,7 +660,16 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     // ---- sub-batches: the can_see sweep of sub-batch i+1 (stream_cs) overlaps the round loop
     // of sub-batch i (main stream); a kernel boundary separates producer and consumer of a row
     std::vector<int64_t> cut{first};
-    if (K >= 65536 && c->pipe > 1) {
+    if (const char* cs_ = getenv("SW_CUTS"); cs_ && K >= 65536) {  // tuning hook: cut points as fractions of K
+        for (const char* q = cs_; *q;) {
+            char* end = nullptr;
+            const double f = strtod(q, &end);
+            if (end == q) break;
+            const int64_t bnd = ((first + (int64_t)(f * (double)K)) >> 12) << 12;
+            if (bnd > cut.back() && bnd < first + K) cut.push_back(bnd);
+            q = *end ? end + 1 : end;
+        }
+    } else if (K >= 65536 && c->pipe > 1) {
         // a short first sub-batch (its sweep is the only one nothing overlaps), then even parts
         const int64_t head = K / 16;
         for (int s_ = 0; s_ < c->pipe; ++s_) {
@@ -747,7 +756,20 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         if (row0_dirty)
             HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_chain_len.p, clen.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        const bool dbg_t = getenv("SW_DEBUG_TIMING") != nullptr;
+        const auto dbg_t0 = std::chrono::steady_clock::now();
+        const int64_t dbg_it0 = c->ctr.round_iterations;
+        if (dbg_t) (void)hipStreamSynchronize(c->stream);  // separates "waiting for the sweep" from the loop itself
+        const auto dbg_t1 = std::chrono::steady_clock::now();
         CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], &tally_ms, &tally_launches));
+        if (dbg_t) {
+            const auto dbg_t2 = std::chrono::steady_clock::now();
+            const double w = std::chrono::duration<double, std::milli>(dbg_t1 - dbg_t0).count();
+            const double l = std::chrono::duration<double, std::milli>(dbg_t2 - dbg_t1).count();
+            const int64_t its = c->ctr.round_iterations - dbg_it0;
+            fprintf(stderr, "[sw] sub-batch %d: %lld events, waited %.3f ms for the sweep, loop %.3f ms, %lld iterations (%.1f us each)\n",
+                    i, (long long)(cut[i + 1] - cut[i]), w, l, (long long)its, its ? l * 1e3 / (double)its : 0.0);
+        }
         // host mirror of the per-member front round
         const int R = c->R;
         std::vector<int32_t> rows((size_t)std::max(R - r_start, 0) * np);
