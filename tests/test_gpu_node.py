@@ -29,12 +29,16 @@ def test_node_mainloop_matches_oracle(pkg):
     orig_rb = node_mod.crypto.randombytes
     node_mod.crypto.randombytes = lambda k: bytes(rng.getrandbits(8) for _ in range(k))
     node_mod.Node.divide_rounds = recording
+    clock = iter(range(1, 1 << 30))  # deterministic clock
+    orig_time = node_mod.time
+    node_mod.time = lambda: 1.0e9 + 0.001 * next(clock)
     try:
         with contextlib.redirect_stdout(io.StringIO()):
             nodes = pkg.test(4, 400)
     finally:
         node_mod.Node.divide_rounds = orig
         node_mod.crypto.randombytes = orig_rb
+        node_mod.time = orig_time
     assert len(nodes) == 4
     for nd in nodes:
         ids, N = nd._ids, len(nd._ids)

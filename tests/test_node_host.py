@@ -15,6 +15,8 @@ def test_node_main_loop_on_oracle_backend(pkg, monkeypatch):
     monkeypatch.setattr(pkg.node, "Hashgraph", oracle_backend.OracleHashgraph)
     rng = random.Random(20260921)  # seeded gossip: a 4-member hashgraph can also stall for a while
     monkeypatch.setattr(pkg.node.crypto, "randombytes", lambda k: bytes(rng.getrandbits(8) for _ in range(k)))
+    clock = iter(range(1, 1 << 30))  # and a deterministic clock: nothing in this test depends on the wall time
+    monkeypatch.setattr(pkg.node, "time", lambda: 1.0e9 + 0.001 * next(clock))
     with contextlib.redirect_stdout(io.StringIO()):
         nodes = pkg.test(4, 300)
     assert len(nodes) == 4
