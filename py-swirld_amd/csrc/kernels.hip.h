@@ -661,6 +661,25 @@ __device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v));
         }                                                                                 \
     } while (0)
 
+// Start of a round-loop run: the loop state and the per-member buffers in ONE launch (a small
+// call would otherwise pay five separate copies / fills, ~10 us each).
+__global__ void __launch_bounds__(1024)
+k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap) {
+    if (threadIdx.x == 0) {
+        RState t{};
+        t.r = r_start;
+        t.N = N;
+        t.ncap = ncap;
+        B.st[0] = t;
+    }
+    for (int i = threadIdx.x; i < 2 * npad; i += blockDim.x) {
+        B.unres[i] = 0;
+        B.found[i] = SW_INF;
+        B.farslot[i] = SW_INF;
+        B.force[i] = 0;
+    }
+}
+
 // Wave and workgroup reductions for the resolve step.  LDS atomics on one address with a
 // different value per lane are expanded by the compiler into a 64-trip scalar loop (~2 us on the
 // critical path of every iteration): butterflies + one LDS slot per wave + ONE barrier instead.

@@ -81,6 +81,9 @@ struct sw_ctx {
     DBuf<unsigned char> d_cons, d_newc;
     DBuf<u64> d_Sw;
     int Sw_rows = 0;
+    bool debug_timing = false;   // SW_DEBUG_TIMING=1
+    double stage_us[8] = {0};    // sw_divide_rounds host stages: sweeps enqueued, loop set-up, round loop, front rows, aux launches, final syncs
+    int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force;
     DBuf<u64> d_Mb;
@@ -536,24 +539,22 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans) {
 template <int NW>
 int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, float* tally_ms_out, int* tally_launches_out) {
     const int np = c->npad, K = c->K;
-    RState init{};
-    init.r = r_start;
-    init.N = (int)limit;
-    init.ncap = c->NEARCAP;
-    HIPCHK(c, hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_unres.p, 0, 2 * np * sizeof(int32_t), c->stream));
-    CHK(fill_i32(c, c->d_found.p, 2 * np, SW_INF));
-    CHK(fill_i32(c, c->d_farslot.p, 2 * np, SW_INF));
-    HIPCHK(c, hipMemsetAsync(c->d_force.p, 0, 2 * np * sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
+                       (int)limit, c->NEARCAP);
+    c->ctr.kernel_launches++;
     std::vector<Span> tally_spans;
     RState st{};
     int launched = 0;
     // first shot: the predicted number of iterations for this many events (from the
     // iterations-per-event rate of earlier runs), then short top-ups until the loop reports done
-    int shot = c->BATCH;
+    // without a measured rate: about one round per 11.7 n events (SURVEY.md §8 probe) plus the
+    // round in progress — a small call must not pay for a long first shot
+    int shot = std::min<int64_t>(c->BATCH, 2 + (n_new_events / (12 * (int64_t)c->n) + 1) * 2);
     if (c->stat_iters > 0 && c->stat_events > 0) {
         const double pred = (double)c->stat_iters / (double)c->stat_events * (double)n_new_events;
-        shot = std::max(2, (int)(pred * 0.97));
+        static const double factor = getenv("SW_SHOT_FACTOR") ? atof(getenv("SW_SHOT_FACTOR")) : 1.0;
+        static const int extra = getenv("SW_SHOT_EXTRA") ? atoi(getenv("SW_SHOT_EXTRA")) : 2;
+        shot = std::max(2, (int)(pred * factor) + extra);
     }
     shot = std::min(shot, 4096) & ~1;
     for (;;) {
@@ -568,7 +569,7 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
         if ((int64_t)launched > (int64_t)c->max_height + 2 + c->N / K + 4096)
             return fail(c, SW_EIO, "round loop did not terminate after %d iterations (r=%d)", launched, st.r);
-        shot = launched < 48 ? 8 : 4;
+        shot = launched < 8 ? 2 : (launched < 48 ? 8 : 4);
     }
     if (n_new_events >= 4096) {  // keep the rate estimate to runs where it means something
         c->stat_iters += st.iter;
@@ -652,10 +653,25 @@ void height_span(const sw_ctx* c, int64_t a, int64_t b, int* hmin, int* hmax) {
     *hmax = hi;
 }
 
+// host-side stage clock of sw_divide_rounds (SW_DEBUG_TIMING=1: averages printed by sw_destroy)
+struct StageClock {
+    bool on;
+    std::chrono::steady_clock::time_point last;
+    explicit StageClock(bool on_) : on(on_) { if (on) last = std::chrono::steady_clock::now(); }
+    void mark(double* acc) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        *acc += std::chrono::duration<double, std::micro>(now - last).count();
+        last = now;
+    }
+};
+
 template <int NW>
 int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     const int np = c->npad, n = c->n;
     c->ev_used = 0;
+    StageClock clk(c->debug_timing);
+    c->stage_calls += 1;
     Span sp_total = span_begin(c);
     // ---- sub-batches: the can_see sweep of sub-batch i+1 (stream_cs) overlaps the round loop
     // of sub-batch i (main stream); a kernel boundary separates producer and consumer of a row
@@ -719,6 +735,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         HIPCHK(c, hipEventRecord(c->cs_events[i], cs));
     }
     if (c->profiling) (void)hipEventRecord(cs_t1, cs);
+    clk.mark(&c->stage_us[0]);
 
     // ---- round loops, one per sub-batch, each over the events visible so far
     CHK(ensure_rounds(c, std::max(c->R, 1) + c->BATCH + 4));
@@ -756,7 +773,8 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         if (row0_dirty)
             HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_chain_len.p, clen.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        const bool dbg_t = getenv("SW_DEBUG_TIMING") != nullptr;
+        clk.mark(&c->stage_us[1]);
+        const bool dbg_t = c->debug_timing && K >= 65536;
         const auto dbg_t0 = std::chrono::steady_clock::now();
         const int64_t dbg_it0 = c->ctr.round_iterations;
         if (dbg_t) (void)hipStreamSynchronize(c->stream);  // separates "waiting for the sweep" from the loop itself
@@ -770,6 +788,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             fprintf(stderr, "[sw] sub-batch %d: %lld events, waited %.3f ms for the sweep, loop %.3f ms, %lld iterations (%.1f us each)\n",
                     i, (long long)(cut[i + 1] - cut[i]), w, l, (long long)its, its ? l * 1e3 / (double)its : 0.0);
         }
+        clk.mark(&c->stage_us[2]);
         // host mirror of the per-member front round
         const int R = c->R;
         std::vector<int32_t> rows((size_t)std::max(R - r_start, 0) * np);
@@ -781,6 +800,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             for (int r = R - 1; r >= r_start; --r)
                 if (rows[(size_t)(r - r_start) * np + m] != SW_INF) { c->front[m] = std::max(c->front[m], r); break; }
         clen_prev.swap(clen);
+        clk.mark(&c->stage_us[3]);
         // The rounds of every event below `limit` are final now (later sub-batches only add lo
         // entries that compare greater than every existing event), so their round numbers,
         // sees-masks, witness rows and voter masks are produced right away on a third stream,
@@ -800,6 +820,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             c->ctr.kernel_launches += 2;
             CHK(launch_voter_masks<NW>(c, r_start, R, ax));
         }
+        clk.mark(&c->stage_us[4]);
     }
     span_end(c, sp_rl);
 
@@ -811,6 +832,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream_cs));
     HIPCHK(c, hipGetLastError());
+    clk.mark(&c->stage_us[5]);
     c->sw_dirty_from = std::max(R, 1);  // voter masks are up to date
     if (first + K == c->N) std::copy(c->head.begin(), c->head.end(), c->divided_head.begin());
     else for (int64_t e = first; e < first + K; ++e) c->divided_head[c->cr[e]] = (int32_t)e;
@@ -1118,6 +1140,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
+    c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
     if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
         if (hipMalloc(&c->d_dbg, (size_t)SW_DBG_MAX_ITERS * 32 * 8) != hipSuccess) c->d_dbg = nullptr;
         else (void)hipMemset(c->d_dbg, 0, (size_t)SW_DBG_MAX_ITERS * 32 * 8);
@@ -1210,6 +1233,12 @@ int sw_destroy(sw_ctx* c) {
     if (!c) return SW_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->debug_timing && c->stage_calls > 0) {
+        const double k = 1.0 / (double)c->stage_calls;
+        fprintf(stderr, "[sw] sw_divide_rounds host stages, us per call over %lld calls: sweeps enqueued %.1f, loop set-up %.1f, "
+                "round loop %.1f, front rows %.1f, aux launches %.1f, final syncs %.1f\n", (long long)c->stage_calls,
+                c->stage_us[0] * k, c->stage_us[1] * k, c->stage_us[2] * k, c->stage_us[3] * k, c->stage_us[4] * k, c->stage_us[5] * k);
+    }
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
     dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_scat_idx); dfree(c->d_scat_val); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
