@@ -640,6 +640,8 @@ struct LoopBufs {
     int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
     int* farslot;     // [2][npad] smallest candidate slot that was FAR (not tallied; INF: none)
     int* force;       // [2][npad] tally the member's cursor candidate even though it is far
+    int* cand;        // [npad][KPS] candidate table of the next tally launch: entry 0 = the event before
+                      // the member's cursor (self-parent of slot 0), entry 1 + j = slot j; -1 = none
     u64* dbg;         // diagnostics (SW_DEBUG_CLOCKS=1): [iteration][32] wall-clock stamps, else null
 };
 
@@ -910,7 +912,12 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         const int wmx = wave_max_i32(live ? maxc : -1);
         const int wsm = wave_sum_i32(evaluated);
         if (rl == 0) { s_red[0][3][rw] = wmx; s_red[1][3][rw] = wsm; }
-        if (member) s_thr[c] = thr;
+        if (member) {
+            s_thr[c] = thr;
+            s_cp[c] = live ? cs + curc : -1;  // (the three arrays are free again after the inheritance step)
+            s_ln[c] = live;
+            s_res[c] = curc > 0;
+        }
         __syncthreads();
         for (int w = 0; w < nwv; ++w) {
             const int m = s_red[0][3][w];
@@ -919,6 +926,25 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         }
     }
     SW_STAMP(stamp, iter, 13);
+    // Candidate table for the tally (saves it a dependent round trip): workgroup b publishes the
+    // window of member b.  The load is issued here and the store deferred behind the band rows, so
+    // that it costs this kernel no round trip of its own.
+    const int KPS = K < 32 ? 32 : 64;
+    int cand_v = -1;
+    const bool cand_mine = (int)blockIdx.x < npad && (int)threadIdx.x < KPS;
+    {
+        auto window = [&](int m) -> int {
+            const int j = (int)threadIdx.x - 1;
+            const int base = s_cp[m], lv = s_ln[m];
+            return (base >= 0 && j < lv && (j >= 0 || s_res[m])) ? chain_ev[base + j] : -1;
+        };
+        if (cand_mine) cand_v = window(blockIdx.x);
+        if ((int)threadIdx.x < KPS)  // fewer workgroups than members (tuning runs): the rest right away
+            for (int m = blockIdx.x + gridDim.x; m < npad; m += gridDim.x) B.cand[(size_t)m * KPS + threadIdx.x] = window(m);
+    }
+    auto flush_cand = [&]() {
+        if (cand_mine) B.cand[(size_t)blockIdx.x * KPS + threadIdx.x] = cand_v;
+    };
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
     // (hops beyond the cap are rebuilt from their rows by the tally kernel)
     int mask_from = mlo;
@@ -963,13 +989,13 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     // ---- band masks
     SW_STAMP(stamp, iter, sb + 5);
     if (B.dbg && stamp && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb + 7] = (u64)(need_mask ? mhi - mask_from : 0);
-    if (done || !need_mask) return;
+    if (done || !need_mask) { flush_cand(); return; }
     const int lane = lane_id();
     const int wpb = blockDim.x >> 6;
     // the writer block finishes later than the others (it publishes the state): it takes no
     // share of the band, so that the kernel ends with the band and not with its stores
     const int skipw = gridDim.x > 1 ? 1 : 0;
-    if (skipw && writer) return;
+    if (skipw && writer) { flush_cand(); return; }
     const int wave = (blockIdx.x - skipw) * wpb + (threadIdx.x >> 6);
     const int nwaves = (gridDim.x - skipw) * wpb;
     int t_[NW];
@@ -1007,6 +1033,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
                 }
         }
     }
+    flush_cand();
     SW_STAMP(stamp, iter, sb + 6);
 }
 
@@ -1343,8 +1370,8 @@ k_tally_bits(LoopBufs B, int par, int K,
     __shared__ __attribute__((aligned(16))) int s_pk[4][Gm::PK_INTS];
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.found); pin_arg(B.farslot);
-    pin_arg(B.force); pin_arg(B.dbg); pin_arg(par); pin_arg(K); pin_arg(chain_start); pin_arg(chain_len);
-    pin_arg(chain_ev); pin_arg(L); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
+    pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand); pin_arg(par); pin_arg(K);
+    pin_arg(L); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
     int* found = B.found + pb;
@@ -1353,12 +1380,15 @@ k_tally_bits(LoopBufs B, int par, int K,
     const int wv = blockIdx.x * 4 + wib;
     const int cm = wv / K, cj = wv - cm * K;  // member, candidate slot
     // Round trip 1: everything addressed by the launch parameters alone, issued before the first
-    // branch.  Round trip 2: the candidate and its self-parent (the previous event of the same
-    // chain: divide_rounds refuses forks, and creator(e) = cm by construction).  Round trip 3:
-    // its can_see row and other-parent.  Round trip 4: the gathered hop masks.
+    // branch — including the candidate and its self-parent (the previous event of the same chain:
+    // divide_rounds refuses forks, and creator(e) = cm by construction) from the table
+    // k_resolve_band published.  Round trip 2: its can_see row and other-parent.  Round trip 3:
+    // the gathered hop masks.
+    const int KPS = K < 32 ? 32 : 64;
     const int s_done = st->done, mlo = st->mlo, mhi = st->mhi;
-    const int un = B.unres[pb + cm], cu = B.cur[pb + cm], frc = B.force[pb + cm];
-    const int ccs = chain_start[cm], ccl = chain_len[cm];
+    const int un = B.unres[pb + cm], frc = B.force[pb + cm];
+    const int e = B.cand[(size_t)cm * KPS + cj + 1];  // published by k_resolve_band (-1: no such candidate)
+    const int spe = B.cand[(size_t)cm * KPS + cj];
     int thr[NW], P[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
@@ -1368,11 +1398,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     const int it_ = stamp ? st->iter - 1 : 0;
     if (stamp && !s_done && it_ < SW_DBG_MAX_ITERS) B.dbg[(size_t)it_ * 32 + sb] = wall_clock64();
     SW_STAMP(stamp && !s_done, it_, sb + 1);
-    if (s_done || !un) return;
-    const int cp = cu + cj;
-    if (cp >= ccl) return;
-    const int e = chain_ev[ccs + cp];
-    const int spe = cp > 0 ? chain_ev[ccs + cp - 1] : -1;
+    if (s_done || !un || e < 0) return;
     const int ce = cm;
     int* pk = s_pk[wib];
     SW_STAMP(stamp, it_, sb + 2);

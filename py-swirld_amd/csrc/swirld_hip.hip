@@ -85,7 +85,7 @@ struct sw_ctx {
     double stage_us[8] = {0};    // sw_divide_rounds host stages: sweeps enqueued, loop set-up, round loop, front rows, aux launches, final syncs
     int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
-    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force, d_cand;
     DBuf<u64> d_Mb;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;
@@ -454,6 +454,7 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.found = c->d_found.p;
     B.farslot = c->d_farslot.p;
     B.force = c->d_force.p;
+    B.cand = c->d_cand.p;
     B.dbg = c->d_dbg;
     return B;
 }
@@ -1130,7 +1131,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->lo0_h.assign(c->npad, SW_INF);
     c->NEARCAP = std::max(64 * c->npad, 4096);
     c->MCAP = std::max(1024 * c->npad, 65536);
-    if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, atoi(s));
+    if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, std::min(63, atoi(s)));  // the candidate table has 64 columns
     if (const char* s = getenv("SW_BAND")) c->NEARCAP = std::max(64, atoi(s));
     if (const char* s = getenv("SW_BAND_MAX")) c->MCAP = std::max(64, atoi(s));
     c->MCAP = std::max(c->MCAP, c->NEARCAP);
@@ -1196,6 +1197,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_found, 2 * np, 0));
     CCHK(dgrow(c, c->d_farslot, 2 * np, 0));
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
+    CCHK(dgrow(c, c->d_cand, (size_t)np * 64, 0));
     CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_chain_start, np, 0));
@@ -1246,7 +1248,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
-    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_Mb);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
