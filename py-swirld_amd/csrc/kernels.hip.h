@@ -640,7 +640,7 @@ struct LoopBufs {
     int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
     int* farslot;     // [2][npad] smallest candidate slot that was FAR (not tallied; INF: none)
     int* force;       // [2][npad] tally the member's cursor candidate even though it is far
-    int* cand;        // [npad][KPS] candidate table of the next tally launch: entry 0 = the event before
+    int* cand;        // [2][npad][64] candidate table of the next tally launch: entry 0 = the event before
                       // the member's cursor (self-parent of slot 0), entry 1 + j = slot j; -1 = none
     u64* dbg;         // diagnostics (SW_DEBUG_CLOCKS=1): [iteration][32] wall-clock stamps, else null
 };
@@ -772,7 +772,9 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         evaluated = jf != SW_INF ? jf : offered;
         if (fnd != SW_INF && fnd < jf) {
             my_pos_next = curc + fnd;
-            my_lo_next = chain_ev[cs + my_pos_next];
+            // = chain_ev[cs + my_pos_next], from the window the previous launch published for this
+            // member (an L2 hit instead of a miss on the chain index)
+            my_lo_next = B.cand[((size_t)par * npad + c) * 64 + 1 + fnd];
             // the next round's window of this member starts here; fetch its last candidate in the
             // same memory round trip (used for the band range if the round is entered right away)
             spec_cur = my_pos_next;
@@ -940,10 +942,11 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         };
         if (cand_mine) cand_v = window(blockIdx.x);
         if ((int)threadIdx.x < KPS)  // fewer workgroups than members (tuning runs): the rest right away
-            for (int m = blockIdx.x + gridDim.x; m < npad; m += gridDim.x) B.cand[(size_t)m * KPS + threadIdx.x] = window(m);
+            for (int m = blockIdx.x + gridDim.x; m < npad; m += gridDim.x)
+                B.cand[((size_t)(1 - par) * npad + m) * 64 + threadIdx.x] = window(m);
     }
     auto flush_cand = [&]() {
-        if (cand_mine) B.cand[(size_t)blockIdx.x * KPS + threadIdx.x] = cand_v;
+        if (cand_mine) B.cand[((size_t)(1 - par) * npad + blockIdx.x) * 64 + threadIdx.x] = cand_v;
     };
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
     // (hops beyond the cap are rebuilt from their rows by the tally kernel)
@@ -1384,11 +1387,11 @@ k_tally_bits(LoopBufs B, int par, int K,
     // divide_rounds refuses forks, and creator(e) = cm by construction) from the table
     // k_resolve_band published.  Round trip 2: its can_see row and other-parent.  Round trip 3:
     // the gathered hop masks.
-    const int KPS = K < 32 ? 32 : 64;
     const int s_done = st->done, mlo = st->mlo, mhi = st->mhi;
     const int un = B.unres[pb + cm], frc = B.force[pb + cm];
-    const int e = B.cand[(size_t)cm * KPS + cj + 1];  // published by k_resolve_band (-1: no such candidate)
-    const int spe = B.cand[(size_t)cm * KPS + cj];
+    const int* cand = B.cand + ((size_t)(1 - par) * npad + cm) * 64;
+    const int e = cand[cj + 1];  // published by k_resolve_band (-1: no such candidate)
+    const int spe = cand[cj];
     int thr[NW], P[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];

@@ -1197,7 +1197,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_found, 2 * np, 0));
     CCHK(dgrow(c, c->d_farslot, 2 * np, 0));
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
-    CCHK(dgrow(c, c->d_cand, (size_t)np * 64, 0));
+    CCHK(dgrow(c, c->d_cand, (size_t)2 * np * 64, 0));
     CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_chain_start, np, 0));
