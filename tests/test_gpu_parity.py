@@ -172,7 +172,8 @@ def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
     cases = [(48, 15000, 60, 2, 0.2, 0.03), (24, 9000, 61, 2, 0.3, 0.004), (16, 6000, 62, 1, 0.01, 0)]
     oracles = {}
     for k, band, band_max in [("4", "64", None), ("4", "100000", None), ("32", "128", None),
-                              ("8", "64", "64"), ("16", "256", "512")]:
+                              ("8", "64", "64"), ("16", "256", "512"),
+                              ("31", "4096", None), ("63", "256", None), ("1", "4096", None)]:  # candidate-table widths
         monkeypatch.setenv("SW_TALLY_K", k)
         monkeypatch.setenv("SW_BAND", band)
         if band_max:

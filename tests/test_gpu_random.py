@@ -17,7 +17,7 @@ def test_random_shapes(pkg, monkeypatch, seed):
     mode = int(rng.integers(0, 4))
     p0, p1 = float(rng.uniform(0.01, 0.7)), float(rng.uniform(0.002, 0.2))
     chunk = None if rng.random() < 0.4 else int(rng.integers(1, max(2, N // 2)))
-    monkeypatch.setenv("SW_TALLY_K", str(int(rng.choice([4, 8, 16, 32]))))
+    monkeypatch.setenv("SW_TALLY_K", str(int(rng.choice([4, 8, 16, 28, 31, 32, 63]))))
     monkeypatch.setenv("SW_BAND", str(int(rng.choice([64, 256, 4096, 100000]))))
     if rng.random() < 0.5:
         monkeypatch.setenv("SW_BAND_MAX", str(int(rng.choice([64, 1024, 1 << 20]))))
