@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Host-side timing of one bench step, sub-batch by sub-batch: how long each round loop waited
+for its can_see sweep, how long it ran and at what cost per iteration (SW_DEBUG_TIMING=1 makes
+sw_divide_rounds print this).  Usage: python profiles/one_step_timing.py"""
 import importlib, os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("py-swirld_amd")
 n, N = 256, 1000000
 st = pkg.synth_hashgraph(n, N, 3)

@@ -1367,7 +1367,6 @@ k_tally_bits(LoopBufs B, int par, int K,
              const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
     constexpr int G = 64 / W32;          // hop groups
-    constexpr int HPL = (64 * NW) / G;   // hops per lane
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
     using Gm = BitsGeom<NW>;
     __shared__ __attribute__((aligned(16))) int s_pk[4][Gm::PK_INTS];
