@@ -1747,6 +1747,147 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
 }
 
 
+// The same elections with NW threads per candidate (selected with SW_ELECT_IMPL=1, npad * NW <= 1024):
+// thread (j, cx) tallies the 64 voters of mask word j for candidate cx, so a level is a quarter of
+// the dependent chain and four times the waves; the vote words, the first decider of each word
+// and the voter counts are exchanged through LDS, and every thread of a candidate takes the same
+// decision (thread j = 0 records it).  The whole round of voters is staged at once.
+template <int NW, bool UNIT>
+__global__ void __launch_bounds__(1024)
+k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsigned char* __restrict__ coin,
+                  const uint32_t* __restrict__ stake, uint32_t tot2, int coin_period, int max_c, int R,
+                  int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc) {
+    const int r = max_c + blockIdx.x;
+    const int tid = threadIdx.x;
+    const int j = tid / npad, cx = tid - j * npad;  // npad is a multiple of 64: j is uniform in a wave
+    const int x = wit[(size_t)r * npad + cx];
+    {
+        const int nw_r = __syncthreads_count(j == 0 && x >= 0);
+        if (tid == 0 && r > max_c) atomicAdd(&fc->voter_evals, (u64)nw_r);
+    }
+    if (cons[r]) return;
+    __shared__ int s_wv[64 * NW];
+    __shared__ u64 s_m[64 * NW * NW];
+    __shared__ u64 s_V[NW][64 * NW];
+    __shared__ int s_bi[NW][64 * NW];
+    __shared__ int s_bv[NW][64 * NW];
+    __shared__ int s_nv[NW];
+    __shared__ u64 s_p2[16];
+    bool active = x >= 0 && fam[(size_t)r * npad + cx] < 0;
+    u64 V[NW];
+#pragma unroll
+    for (int jj = 0; jj < NW; ++jj) V[jj] = 0;
+    int any_decided = 0;
+    u64 p2 = 0;
+    for (int d = 1; r + d < R; ++d) {
+        if (!__syncthreads_or(active)) break;  // also: every read of the previous level is done
+        const int rv = r + d;
+        const int* wv_row = wit + (size_t)rv * npad;
+        const u64* sw_row = Sw + (size_t)rv * npad * NW;
+        const bool coin_round = (d % coin_period) == 0;
+        s_m[tid] = sw_row[tid];  // blockDim = npad * NW = words of the round's voter masks
+        if (tid < npad) s_wv[tid] = wv_row[tid];
+        __syncthreads();
+        u64 acc = 0;
+        int best_idx = SW_INF, best_v = 0, nv = 0;
+        for (int ci = 0; ci < 64; ++ci) {
+            const int c = j * 64 + ci;
+            const int wv = s_wv[c];  // uniform in the wave
+            if (wv < 0) continue;
+            ++nv;
+            const u64* m = s_m + c * NW;
+            int bitv;
+            if (d == 1) {
+                bitv = (int)((m[cx >> 6] >> (cx & 63)) & 1ull);  // x in s (swirld.py:258)
+            } else {
+                uint32_t yes = 0, tot = 0;
+                if (UNIT) {
+#pragma unroll
+                    for (int jj = 0; jj < NW; ++jj) {
+                        const u64 mm = m[jj];
+                        yes += __popcll(mm & V[jj]);
+                        tot += __popcll(mm);
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < NW; ++jj) {
+                        u64 mm = m[jj];
+                        while (mm) {
+                            const int b = __ffsll((long long)mm) - 1;
+                            mm &= mm - 1;
+                            const uint32_t sk = stake[jj * 64 + b];
+                            tot += sk;
+                            if ((V[jj] >> b) & 1ull) yes += sk;
+                        }
+                    }
+                }
+                const uint32_t no = tot - yes;
+                const int v = !(no > yes);  // majority(): tie -> True (swirld.py:24-27)
+                const uint32_t t = v ? yes : no;
+                const bool sm = 3u * t > tot2;
+                if (!coin_round) {
+                    if (sm && wv < best_idx) { best_idx = wv; best_v = v; }
+                    bitv = v;
+                } else {
+                    bitv = sm ? v : (int)coin[wv];  // swirld.py:267-272
+                }
+            }
+            acc |= (u64)bitv << ci;
+        }
+        s_V[j][cx] = acc;
+        s_bi[j][cx] = best_idx;
+        s_bv[j][cx] = best_v;
+        if (cx == 0) s_nv[j] = nv;
+        __syncthreads();
+        int nvoters = 0;
+        best_idx = SW_INF;
+        best_v = 0;
+#pragma unroll
+        for (int jj = 0; jj < NW; ++jj) {
+            V[jj] = s_V[jj][cx];
+            nvoters += s_nv[jj];
+            const int bi = s_bi[jj][cx];
+            if (bi < best_idx) { best_idx = bi; best_v = s_bv[jj][cx]; }
+        }
+        if (active && d >= 2) {
+            if (!coin_round && best_idx != SW_INF) {
+                active = false;
+                any_decided = 1;
+                if (j == 0) {
+                    fam[(size_t)r * npad + cx] = (signed char)best_v;  // swirld.py:263
+                    int le = 0;  // voters after the first decider never evaluate x
+                    for (int c = 0; c < npad; ++c) {
+                        const int wv = s_wv[c];
+                        le += (wv >= 0 && wv <= best_idx);
+                    }
+                    p2 += le;
+                }
+            } else if (j == 0) {
+                p2 += nvoters;
+            }
+        }
+    }
+    const int x_open = j == 0 && x >= 0 && fam[(size_t)r * npad + cx] < 0;
+    const int n_open = __syncthreads_count(x_open);
+    const int dec = __syncthreads_or(any_decided);
+    if (tid == 0 && dec && n_open == 0) {  // swirld.py:274-277
+        newc[r] = 1;
+        cons[r] = 1;
+    }
+    {   // one atomic per workgroup
+        u64 t = p2;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += (u64)__shfl_xor((long long)t, off);
+        if ((tid & 63) == 0) s_p2[tid >> 6] = t;
+        __syncthreads();
+        if (tid == 0) {
+            u64 tot = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_p2[w];
+            if (tot) atomicAdd(&fc->majority_evals, tot);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // find_order (swirld.py:280-311), fork-free form.  Because "w sees x" (swirld.py:291-292:
 // can_see[w][c] is at least as high as x on creator c's chain) is inherited by every

@@ -95,6 +95,7 @@ struct sw_ctx {
     int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
 
     // tuning
+    int elect_impl = 1; // 1: NW threads per candidate where npad * NW <= 1024 (k_elections_split), 0: one thread per candidate
     int K = 28;        // candidates per member per tally launch: 7 waves per SIMD (the 8th slot is
                        // taken by the concurrent can_see sweep; 29+ costs a second wave generation)
     int MCAP = 0;      // largest band (events) the mask table can hold
@@ -870,7 +871,22 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     if (c->sw_dirty_from < R || R > c->Sw_rows) CHK(launch_voter_masks<NW>(c, std::min(c->sw_dirty_from, R), R, c->stream));
     c->sw_dirty_from = std::max(R, 1);
     HIPCHK(c, hipMemsetAsync(c->d_newc.p, 0, R, c->stream));
-    if (R > max_c) {
+    bool split_done = false;
+    if constexpr (NW >= 2 && NW <= 4) {  // NW threads per candidate (see k_elections_split): npad * NW <= 1024
+        if (R > max_c && c->elect_impl == 1) {
+            if (c->unit_stake)
+                hipLaunchKernelGGL((k_elections_split<NW, true>), dim3(R - max_c), dim3(np * NW), 0, c->stream, (const int*)c->d_wit.p,
+                                   (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
+                                   tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
+            else
+                hipLaunchKernelGGL((k_elections_split<NW, false>), dim3(R - max_c), dim3(np * NW), 0, c->stream, (const int*)c->d_wit.p,
+                                   (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
+                                   tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
+            c->ctr.kernel_launches++;
+            split_done = true;
+        }
+    }
+    if (!split_done && R > max_c) {
         if (c->unit_stake)
             hipLaunchKernelGGL((k_elections<NW, true>), dim3(R - max_c), dim3(np), 0, c->stream, (const int*)c->d_wit.p,
                                (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
@@ -1141,6 +1157,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
+    if (const char* s = getenv("SW_ELECT_IMPL")) c->elect_impl = atoi(s);
     c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
     if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
         if (hipMalloc(&c->d_dbg, (size_t)SW_DBG_MAX_ITERS * 32 * 8) != hipSuccess) c->d_dbg = nullptr;

@@ -215,6 +215,25 @@ def test_kernel_variants_agree(pkg, monkeypatch, cansee, tally, ring_h):
         h.close()
 
 
+@pytest.mark.parametrize("elect", ["0", "1"])
+def test_election_kernel_variants_agree(pkg, monkeypatch, elect):
+    """One thread per candidate (0) and NW threads per candidate (1, the default where
+    npad * NW <= 1024) against the oracle: decisions, consensus rounds and the V / P2 counters,
+    batch and incremental schedules, four generator modes."""
+    monkeypatch.setenv("SW_ELECT_IMPL", elect)
+    for n, N, seed, mode, p0, p1, chunk in [(130, 14000, 75, 0, 0, 0, None), (256, 30000, 76, 2, 0.2, 0.05, 7000),
+                                            (100, 9000, 77, 1, 0.02, 0, 1500), (200, 20000, 78, 3, 0.6, 0, None)]:
+        stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+        o, ncs_o = oracle_run(n, stream, chunk=chunk)
+        h, ncs_h = hip_run(pkg, n, stream, chunk=chunk)
+        assert ncs_h == ncs_o
+        assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+        if chunk is None:  # the counters are compared for batch schedules (as in test_hip_matches_oracle)
+            ch, co = h.counters(), o.counters()
+            assert ch["voter_evals"] == co["voter_evals"] and ch["majority_evals"] == co["majority_evals"]
+        h.close()
+
+
 @pytest.mark.parametrize("pipe", ["1", "3", "8"])
 def test_pipelined_subbatches_match_oracle(pkg, monkeypatch, pipe):
     """One big divide_rounds call is internally split into sub-batches whose can_see sweeps
