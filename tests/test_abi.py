@@ -30,6 +30,35 @@ def test_header_symbols_exported(pkg):
     assert lib.sw_version() == 1
 
 
+def test_integration_stub_matches_the_abi(pkg):
+    """The ctypes binding shown in INTEGRATION.md (what a maintainer of the reference would add)
+    is executed against the real library: every entry point it binds exists, and its argument
+    lists have the arity of the header prototypes and of the package's own ctypes table."""
+    import ctypes as ct
+    import importlib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("# --- add to swirld.py"):]
+    block = block[:block.index("```")]
+    lines = [ln for ln in block.splitlines() if re.match(r"_sw\.sw_[a-z_]+\.(argtypes|restype)\s*=", ln) or ln.startswith("_P =")]
+    assert len(lines) >= 9
+    env = {"ct": ct, "_sw": ct.CDLL(pkg.LIB_PATH)}
+    exec("\n".join(lines), env)
+    L = importlib.import_module("py-swirld_amd._lib")
+    header = open(os.path.join(ROOT, "include", "swirld_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for ln in lines:
+        m = re.match(r"_sw\.(sw_[a-z_]+)\.argtypes", ln)
+        if not m:
+            continue
+        fn = m.group(1)
+        bound = getattr(env["_sw"], fn).argtypes
+        proto = re.search(r"\b%s\s*\(([^)]*)\)" % fn, header).group(1)
+        assert len(bound) == len([a for a in proto.split(",") if a.strip()]), fn
+        assert len(bound) == len(L.SIGNATURES[fn][1]), fn
+    for fn in re.findall(r"_sw\.(sw_[a-z_]+)\(", block):  # every call made by the stub is a real entry point
+        assert fn in L.SIGNATURES, fn
+
+
 def test_synth_is_a_valid_forkfree_dag(pkg):
     for mode, p0, p1 in [(0, 0, 0), (1, 0.05, 0), (2, 0.25, 0.05), (3, 0.5, 0)]:
         n, N = 12, 3000
