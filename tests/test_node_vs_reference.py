@@ -103,3 +103,50 @@ def test_simulation_matches_reference(pkg, monkeypatch, n, turns, seed):
     # (how far the total order gets depends on the process's hash seed — the gossip partner is
     # picked from a set of bytes keys, swirld.py:322 — so no progress is demanded per case)
     assert all(len(nd.hg) > turns // 4 for nd in ref_nodes)
+
+
+def test_is_valid_event_agrees_with_reference(pkg, monkeypatch):
+    """N3, host side: the same accept / reject decisions as swirld.py:97-108 for
+    well-formed events and for every way of malforming one (signature, hash, parents)."""
+    sw = refharness.import_reference()
+    import pysodium
+    monkeypatch.setattr(pkg.node, "Hashgraph", oracle_backend.OracleHashgraph)
+    monkeypatch.setattr(pkg.node, "dumps", _class_free_dumps)
+    monkeypatch.setattr(sw, "dumps", _class_free_dumps)
+    kps = [pysodium.crypto_sign_seed_keypair(bytes([i]) * 32) for i in range(3)]
+    stake = {kp[0]: 1 for kp in kps}
+    monkeypatch.setattr(sw, "time", _clock())        # the same clock on both sides: same root events
+    monkeypatch.setattr(pkg.node, "time", _clock())
+    ref = [sw.Node(kp, {}, 3, stake) for kp in kps]
+    ours = [pkg.Node(kp, {}, 3, stake) for kp in kps]
+    assert [nd.head for nd in ref] == [nd.head for nd in ours]
+    for a, b in zip(ref, ours):  # give node 0 the roots of the others
+        if a is not ref[0]:
+            ref[0].add_event(a.head, a.hg[a.head])
+            ours[0].add_event(b.head, b.hg[b.head])
+    r0, o0 = ref[0], ours[0]
+    good_h, good = r0.new_event(b"x", (r0.head, ref[1].head))
+    cases = [("well-formed", good_h, good)]
+    cases.append(("wrong hash", b"\0" * 32, good))
+    cases.append(("tampered payload", good_h, good._replace(d=b"z")))
+    cases.append(("tampered timestamp", good_h, good._replace(t=good.t + 1)))
+    cases.append(("bad signature", good_h, good._replace(s=bytes(64))))
+    swapped = sw.Event(b"x", (ref[1].head, r0.head), good.t, r0.pk, b"")
+    swapped = swapped._replace(s=pysodium.crypto_sign_detached(_class_free_dumps(tuple(swapped[:-1])), r0.sk))
+    cases.append(("parents swapped (first is not the self-parent)", sw.crypto_generichash(_class_free_dumps(swapped)), swapped))
+    both_mine = sw.Event(b"x", (r0.head, r0.head), good.t, r0.pk, b"")
+    both_mine = both_mine._replace(s=pysodium.crypto_sign_detached(_class_free_dumps(tuple(both_mine[:-1])), r0.sk))
+    cases.append(("other-parent is mine", sw.crypto_generichash(_class_free_dumps(both_mine)), both_mine))
+    unknown = sw.Event(b"x", (r0.head, b"\x07" * 32), good.t, r0.pk, b"")
+    unknown = unknown._replace(s=pysodium.crypto_sign_detached(_class_free_dumps(tuple(unknown[:-1])), r0.sk))
+    cases.append(("unknown parent", sw.crypto_generichash(_class_free_dumps(unknown)), unknown))
+    one_parent = sw.Event(b"x", (r0.head,), good.t, r0.pk, b"")
+    one_parent = one_parent._replace(s=pysodium.crypto_sign_detached(_class_free_dumps(tuple(one_parent[:-1])), r0.sk))
+    cases.append(("one parent", sw.crypto_generichash(_class_free_dumps(one_parent)), one_parent))
+    seen = set()
+    for name, h, ev in cases:
+        mine = pkg.Event(*ev)
+        want = r0.is_valid_event(h, ev)
+        assert o0.is_valid_event(h, mine) == want, name
+        seen.add(want)
+    assert seen == {True, False}
