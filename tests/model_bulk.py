@@ -300,3 +300,152 @@ def bulk_rounds_v2(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None):
         lo.append(lo_next)
         pos = pos_next
     return L, np.array(lo, np.int64).astype(np.int32), stats
+
+
+def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_after=2):
+    """bulk_rounds_v2 plus GALLOPING for long runs of false candidates (a few members creating
+    most of the events: thousands of chain positions per round, K per iteration).  After
+    `gallop_after` consecutive windows without a passing candidate a member's window becomes
+    STRIDED (positions cur, cur+K, cur+2K, ...): the predicate is monotone along the chain, so a
+    failing slot rules out everything before it, and a passing slot f > 0 brackets the first
+    passing position in (slot f-1, slot f], which one ordinary window covers.  A strided window
+    falls back to an ordinary one whenever it meets a far candidate or the end of the chain.
+    Prototype of the next kernel change; the rest is bulk_rounds_v2:
+    Round loop with the inheritance shortcut for FAR candidates (kernel structure of
+    k_resolve_band / k_tally_* since the slow-member fix):
+      * a candidate e is FAR when max(sp[e], op[e]) lies beyond the band; far candidates are
+        never tallied;
+      * all earlier positions of e's creator being false, round[e] >= r+1 iff the other-parent
+        q = op[e] has round >= r+1, i.e. q >= lo[r+1][creator(q)]; that is known once creator(q)
+        is resolved for this round, and definitely false when q lies before that creator's
+        cursor; otherwise the member waits for the next iteration;
+      * a far candidate whose parents both have round <= r needs a real tally: the band is
+        doubled (up to CAPMAX) so that it becomes near."""
+    N = len(cr)
+    stake = np.asarray(stake, np.int64)
+    T = int(stake.sum())
+    NEARCAP = NEARCAP or 8 * n
+    CAPMAX = CAPMAX or max(N, NEARCAP)
+    L = can_see_rows(n, cr, sp, op)
+    chains = [np.nonzero(cr == c)[0].astype(np.int64) for c in range(n)]
+    lo = [np.array([ch[0] if len(ch) else INF for ch in chains], np.int64)]
+    pos = np.zeros(n, np.int64)
+    stats = dict(iters=0, evals=0, waits=0, grows=0, strided=0, refines=0)
+    while True:
+        lo_r = lo[-1]
+        active = lo_r < INF
+        if not active.any():
+            lo.pop()
+            break
+        mlo = int(lo_r[active].min())
+        ncap = NEARCAP
+        lo_next = np.full(n, INF, np.int64)
+        pos_next = pos.copy()
+        resolved = ~active            # inactive members: lo[r+1] = INF, known
+        cur = pos.copy()
+        stride = np.ones(n, np.int64)
+        misses = np.zeros(n, np.int64)
+        mhi_done = mlo
+        masks = {}
+        while not resolved.all():
+            stats["iters"] += 1
+            unres = [c for c in range(n) if not resolved[c]]
+            def last_slot(c):  # chain position of the last slot of c's window
+                return min(cur[c] + (K - 1) * stride[c], len(chains[c]) - 1)
+            maxc = max(int(chains[c][last_slot(c)]) for c in unres
+                       if cur[c] < len(chains[c])) if any(cur[c] < len(chains[c]) for c in unres) else mlo
+            mhi = min(N, min(maxc + 1, mlo + ncap))
+            for k in range(mhi_done, mhi):            # band (extension)
+                if k >= lo_r[cr[k]]:
+                    masks[k] = L[k] >= lo_r
+            mhi_done = max(mhi_done, mhi)
+            found = {c: None for c in unres}
+            farslot = {c: None for c in unres}
+            nslots = {c: 0 for c in unres}
+            for c in unres:                            # ---- tally kernel
+                if stride[c] > 1:
+                    stats["strided"] += 1
+                for j in range(K):
+                    p = cur[c] + j * stride[c]
+                    if p >= len(chains[c]):
+                        break
+                    nslots[c] = j + 1
+                    e = int(chains[c][p])
+                    reach = max(int(sp[e]), int(op[e]))
+                    if reach >= mhi_done:              # far: not tallied
+                        if farslot[c] is None:
+                            farslot[c] = j
+                        continue
+                    stats["evals"] += 1
+                    P = L[e].copy()
+                    P[cr[e]] = sp[e]
+                    hits = np.zeros(n, np.int64)
+                    for c2 in np.nonzero(P >= lo_r)[0]:
+                        hits += stake[c2] * masks[int(P[c2])]
+                    if 3 * int(np.count_nonzero(3 * hits > 2 * T)) > 2 * T and found[c] is None:
+                        found[c] = j
+            # ---- resolve
+            newly = {}
+            grow = False
+            refined = set()
+            for c in unres:
+                f, jf = found[c], farslot[c]
+                s_ = int(stride[c])
+                if f is not None and (jf is None or f < jf):
+                    if s_ == 1 or f == 0:
+                        newly[c] = (int(chains[c][cur[c] + f * s_]), cur[c] + f * s_)
+                    else:                              # bracketed: (slot f-1, slot f]
+                        cur[c] += (f - 1) * s_ + 1
+                        stride[c] = 1
+                        refined.add(c)
+                        stats["refines"] += 1
+                elif jf is None:
+                    last = cur[c] + (nslots[c] - 1) * s_   # last evaluated position: false
+                    if s_ == 1 and cur[c] + K >= len(chains[c]):
+                        newly[c] = (INF, None)         # exhausted
+                    elif s_ > 1 and cur[c] + K * s_ >= len(chains[c]):
+                        cur[c] = last + 1              # the tail of the chain: ordinary windows
+                        stride[c] = 1
+                        refined.add(c)
+                    else:
+                        cur[c] = last + 1
+                        misses[c] += 1
+                        if misses[c] >= gallop_after:
+                            stride[c] = K
+                elif s_ > 1 and jf > 0:                # a far slot inside a strided window
+                    cur[c] += (jf - 1) * s_ + 1
+                    stride[c] = 1
+                    refined.add(c)
+                else:
+                    cur[c] += jf * s_                  # near slots before jf are false (jf == 0 if strided)
+                    stride[c] = 1
+            for c in unres:                            # far candidates (uses this iteration's results)
+                if c in newly or c in refined or farslot[c] is None or (found[c] is not None and found[c] < farslot[c]):
+                    continue
+                e = int(chains[c][cur[c]])
+                q = int(op[e])
+                b = int(cr[q])
+                if resolved[b] or b in newly:
+                    ln = lo_next[b] if resolved[b] else newly[b][0]
+                    if q >= ln:
+                        newly[c] = (e, cur[c])
+                    else:
+                        grow = True
+                else:
+                    lb = int(chains[b][cur[b]]) if cur[b] < len(chains[b]) else INF
+                    if q < lb:
+                        grow = True
+                    else:
+                        stats["waits"] += 1
+            for c, (ev, p) in newly.items():
+                resolved[c] = True
+                if ev != INF:
+                    lo_next[c] = ev
+                    pos_next[c] = p
+            if grow:
+                assert ncap < CAPMAX, "model: band cap exhausted"
+                ncap = min(2 * ncap, CAPMAX)
+                stats["grows"] += 1
+        lo.append(lo_next)
+        pos = pos_next
+    return L, np.array(lo, np.int64).astype(np.int32), stats

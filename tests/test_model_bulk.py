@@ -73,3 +73,31 @@ def test_far_candidate_inheritance_model(pkg, n, N, seed, mode, p0, p1, K, cap):
     assert np.array_equal(rnd, o.round)
     assert np.array_equal(wit, o.witnesses())
     assert stats["waits"] > 0 and stats["grows"] > 0
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,K,cap", [
+    (16, 6000, 31, 2, 0.2, 50.0, 4, 64),     # hot members: 3 of 16 create ~90 % of the events
+    (20, 8000, 34, 2, 0.15, 100.0, 8, 128),
+    (12, 4000, 33, 0, 0, 0, 3, 24),          # uniform gossip with a tiny window: galloping misfires
+    (16, 3000, 3, 2, 0.25, 0.01, 4, 32),     # slow members: far candidates inside strided windows
+])
+def test_galloping_window_model(pkg, n, N, seed, mode, p0, p1, K, cap):
+    """Next kernel change, validated here first: after two windows without a
+    passing candidate a member's window becomes strided; exactness vs the oracle, and the
+    iteration count on hot-member DAGs (the weak spot of the current round loop)."""
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    o = Oracle(n)
+    o.append_events(cr, sp, op, t, sig)
+    o.divide_rounds(0, N)
+    one = np.ones(n, np.int64)
+    L3, lo3, st3 = mb.bulk_rounds_v3(n, cr, sp, op, one, K=K, NEARCAP=cap)
+    rnd, S, wit = mb.finalize(n, cr, L3, lo3)
+    assert np.array_equal(rnd, o.round)
+    assert np.array_equal(wit, o.witnesses())
+    _, lo2, st2 = mb.bulk_rounds_v2(n, cr, sp, op, one, K=K, NEARCAP=cap)
+    assert np.array_equal(lo2, lo3)
+    assert st3["strided"] > 0 and st3["refines"] > 0
+    if p1 > 1:  # hot members: far fewer iterations and tallies
+        assert 2 * st3["iters"] < st2["iters"] and 2 * st3["evals"] < st2["evals"]
+    else:       # elsewhere galloping must not cost more than a few percent
+        assert st3["iters"] <= st2["iters"] * 1.1 + 2
