@@ -640,8 +640,10 @@ struct LoopBufs {
     int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
     int* farslot;     // [2][npad] smallest candidate slot that was FAR (not tallied; INF: none)
     int* force;       // [2][npad] tally the member's cursor candidate even though it is far
-    int* cand;        // [2][npad][64] candidate table of the next tally launch: entry 0 = the event before
-                      // the member's cursor (self-parent of slot 0), entry 1 + j = slot j; -1 = none
+    int* cand;        // [2][npad][64] candidate table of the next tally launch: entry 1 + j = event of
+                      // slot j (chain position cursor + j * stride); -1 = none
+    int* gallop;      // [2][npad] window stride (bits 0-7; 1 = contiguous) and consecutive windows without
+                      // a passing candidate (bits 8+) of the member in the current round
     u64* dbg;         // diagnostics (SW_DEBUG_CLOCKS=1): [iteration][32] wall-clock stamps, else null
 };
 
@@ -679,6 +681,7 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap) {
         B.found[i] = SW_INF;
         B.farslot[i] = SW_INF;
         B.force[i] = 0;
+        B.gallop[i] = 1;
     }
 }
 
@@ -708,7 +711,7 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // band event, NW ballots).
 template <int NW>
 __global__ void __launch_bounds__(1024)
-k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int Rcap,
+k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
                const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb) {
@@ -744,6 +747,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     const int fnd = member ? B.found[in + c] : SW_INF;
     const int jf = member ? B.farslot[in + c] : SW_INF;
     int frc = member ? B.force[in + c] : 0;
+    const int gsv = member ? B.gallop[in + c] : 1;
     int evr_now = member ? B.evalround[in + c] : -1, evp_now = member ? B.evalpos[in + c] : 0;
     const int in_lo_next = member ? B.lo_next[in + c] : SW_INF;
     const int in_pos_next = member ? B.pos_next[in + c] : 0;
@@ -767,29 +771,54 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     int evaluated = 0;
     int spec_cur = -1, spec_last = -1;
     int far_wait = 0;  // the cursor candidate is FAR: decide it by inheritance below
+    // GALLOPING (SW_GALLOP, tests/model_bulk.py bulk_rounds_v3): after `gallop_after` consecutive
+    // windows without a passing candidate the member's window is strided (positions cursor,
+    // cursor + K, ...).  The predicate is monotone along the chain: a failing slot rules out
+    // everything before it, a passing slot f > 0 brackets the first passing position in
+    // (slot f-1, slot f], which one contiguous window covers.  A strided window falls back to a
+    // contiguous one at a far candidate and at the end of the chain.
+    int strd = gsv & 0xff, miss = gsv >> 8;
     if (iter > 0 && un) {
-        const int offered = clen - curc < K ? clen - curc : K;
+        // slots offered by the previous launch: positions curc + j * strd < clen, j < K
+        const int offered = strd == 1 ? (clen - curc < K ? clen - curc : K)
+                                      : ((clen - 1 - curc) / strd + 1 < K ? (clen - 1 - curc) / strd + 1 : K);
         evaluated = jf != SW_INF ? jf : offered;
         if (fnd != SW_INF && fnd < jf) {
-            my_pos_next = curc + fnd;
-            // = chain_ev[cs + my_pos_next], from the window the previous launch published for this
-            // member (an L2 hit instead of a miss on the chain index)
-            my_lo_next = B.cand[((size_t)par * npad + c) * 64 + 1 + fnd];
-            // the next round's window of this member starts here; fetch its last candidate in the
-            // same memory round trip (used for the band range if the round is entered right away)
-            spec_cur = my_pos_next;
-            spec_last = chain_ev[cs + (clen - my_pos_next < K ? clen : my_pos_next + K) - 1];
-            un = 0;
+            if (strd == 1 || fnd == 0) {
+                my_pos_next = curc + fnd * strd;
+                // = chain_ev[cs + my_pos_next], from the window the previous launch published for this
+                // member (an L2 hit instead of a miss on the chain index)
+                my_lo_next = B.cand[((size_t)par * npad + c) * 64 + 1 + fnd];
+                // the next round's window of this member starts here; fetch its last candidate in the
+                // same memory round trip (used for the band range if the round is entered right away)
+                spec_cur = my_pos_next;
+                spec_last = chain_ev[cs + (clen - my_pos_next < K ? clen : my_pos_next + K) - 1];
+                un = 0;
+            } else {  // bracketed by a strided window: look at (slot fnd-1, slot fnd] next
+                curc += (fnd - 1) * strd + 1;
+                strd = 1;
+            }
         } else if (jf != SW_INF) {
-            curc += jf;  // the near slots before the first far one are false
-            far_wait = 1;
-            frc = 0;
-        } else if (curc + K >= clen) {  // chain exhausted: no round-(r+1) event of c (yet)
+            if (strd > 1 && jf > 0) {  // a far slot inside a strided window: back to contiguous after the last false slot
+                curc += (jf - 1) * strd + 1;
+                strd = 1;
+            } else {
+                curc += jf * strd;  // the near slots before the first far one are false
+                strd = 1;
+                far_wait = 1;
+                frc = 0;
+            }
+        } else if (strd == 1 && curc + K >= clen) {  // chain exhausted: no round-(r+1) event of c (yet)
             un = 0;
             evr_now = r;
             evp_now = clen;
+        } else if (strd > 1 && curc + K * strd >= clen) {  // the tail of the chain: contiguous windows
+            curc += (offered - 1) * strd + 1;
+            strd = 1;
         } else {
-            curc += K;
+            curc += (offered - 1) * strd + 1;  // = curc + K for a contiguous window
+            if (miss < 255) ++miss;
+            if (gallop_after > 0 && miss >= gallop_after) strd = K < 255 ? K : 255;
         }
     }
     // ---- far candidates (inheritance): every earlier position of c being false, the cursor
@@ -894,6 +923,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
                 need_mask = 1;
                 ncap = NEARCAP;
                 frc = 0;
+                strd = 1;
+                miss = 0;
                 break;
             }
             ++r;  // nothing to do in this round: step to the next one (rare, incremental calls)
@@ -905,8 +936,9 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
     if (done) un = 0;
     SW_STAMP(stamp, iter, sb + 4);
     // candidates of member c in the next tally launch: chain positions [curc, curc + K)
-    const int live = un ? (clen - curc < K ? clen - curc : K) : 0;
-    const int maxc = !live ? -1 : (curc == spec_cur ? spec_last : chain_ev[cs + curc + live - 1]);
+    const int live = !un ? 0 : strd == 1 ? (clen - curc < K ? clen - curc : K)
+                                         : ((clen - 1 - curc) / strd + 1 < K ? (clen - 1 - curc) / strd + 1 : K);
+    const int maxc = !live ? -1 : (curc == spec_cur && strd == 1 ? spec_last : chain_ev[cs + curc + (live - 1) * strd]);
     SW_STAMP(stamp, iter, 12);
     int s_max = -1, s_cnt = 0;
     {   // max(last candidate), sum(evaluated) and the thresholds for the band, one barrier
@@ -918,7 +950,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
             s_thr[c] = thr;
             s_cp[c] = live ? cs + curc : -1;  // (the three arrays are free again after the inheritance step)
             s_ln[c] = live;
-            s_res[c] = curc > 0;
+            s_res[c] = strd;
         }
         __syncthreads();
         for (int w = 0; w < nwv; ++w) {
@@ -938,7 +970,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
         auto window = [&](int m) -> int {
             const int j = (int)threadIdx.x - 1;
             const int base = s_cp[m], lv = s_ln[m];
-            return (base >= 0 && j < lv && (j >= 0 || s_res[m])) ? chain_ev[base + j] : -1;
+            return (base >= 0 && j >= 0 && j < lv) ? chain_ev[base + j * s_res[m]] : -1;
         };
         if (cand_mine) cand_v = window(blockIdx.x);
         if ((int)threadIdx.x < KPS)  // fewer workgroups than members (tuning runs): the rest right away
@@ -976,6 +1008,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int NEARCAP, int MCAP, int 
             B.found[out + c] = SW_INF;
             B.farslot[out + c] = SW_INF;
             B.force[out + c] = frc;
+            B.gallop[out + c] = strd | (miss << 8);
         }
         if (c == 0) {
             RState t = *si;
@@ -1077,7 +1110,6 @@ k_tally_candidates(LoopBufs B, int par, int K,
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
     const int* unres = B.unres + pb;
-    const int* cur = B.cur + pb;
     const int* lo_r = B.lo_r + pb;
     int* found = B.found + pb;
     if (st->done) return;
@@ -1086,10 +1118,8 @@ k_tally_candidates(LoopBufs B, int par, int K,
     const int w = blockIdx.x * 4 + wib;
     const int cm = w / K, cj = w - cm * K;  // member, candidate slot
     if (!unres[cm]) return;
-    const int ccs = chain_start[cm];
-    const int cp = cur[cm] + cj;
-    if (cp >= chain_len[cm]) return;
-    const int e = chain_ev[ccs + cp];
+    const int e = B.cand[((size_t)(1 - par) * npad + cm) * 64 + cj + 1];  // slot cj of the member's window
+    if (e < 0) return;
     const int mlo = st->mlo, mhi = st->mhi;
     u64* hm = s_hm[wib];
     const int ce = cr[e], spe = sp[e];
@@ -1373,7 +1403,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.found); pin_arg(B.farslot);
     pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand); pin_arg(par); pin_arg(K);
-    pin_arg(L); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
+    pin_arg(L); pin_arg(sp); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
     int* found = B.found + pb;
@@ -1382,15 +1412,13 @@ k_tally_bits(LoopBufs B, int par, int K,
     const int wv = blockIdx.x * 4 + wib;
     const int cm = wv / K, cj = wv - cm * K;  // member, candidate slot
     // Round trip 1: everything addressed by the launch parameters alone, issued before the first
-    // branch — including the candidate and its self-parent (the previous event of the same chain:
-    // divide_rounds refuses forks, and creator(e) = cm by construction) from the table
-    // k_resolve_band published.  Round trip 2: its can_see row and other-parent.  Round trip 3:
-    // the gathered hop masks.
+    // branch — including the candidate, from the table k_resolve_band published (creator(e) = cm
+    // by construction).  Round trip 2: its can_see row and both parents.  Round trip 3: the
+    // gathered hop masks.
     const int s_done = st->done, mlo = st->mlo, mhi = st->mhi;
     const int un = B.unres[pb + cm], frc = B.force[pb + cm];
     const int* cand = B.cand + ((size_t)(1 - par) * npad + cm) * 64;
     const int e = cand[cj + 1];  // published by k_resolve_band (-1: no such candidate)
-    const int spe = cand[cj];
     int thr[NW], P[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
@@ -1404,7 +1432,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     const int ce = cm;
     int* pk = s_pk[wib];
     SW_STAMP(stamp, it_, sb + 2);
-    const int ope = op[e];
+    const int ope = op[e], spe = sp[e];
 #pragma unroll
     for (int j = 0; j < NW; ++j) P[j] = L[(size_t)e * npad + j * 64 + lane];
     SW_STAMP(stamp, it_, sb + 3);

@@ -85,7 +85,7 @@ struct sw_ctx {
     double stage_us[8] = {0};    // sw_divide_rounds host stages: sweeps enqueued, loop set-up, round loop, front rows, aux launches, final syncs
     int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
-    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force, d_cand;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;
@@ -95,6 +95,7 @@ struct sw_ctx {
     int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
 
     // tuning
+    int gallop_after = 0; // strided candidate windows after this many windows without a passing candidate (0 = never)
     int elect_impl = 1; // 1: NW threads per candidate where npad * NW <= 1024 (k_elections_split), 0: one thread per candidate
     int K = 28;        // candidates per member per tally launch: 7 waves per SIMD (the 8th slot is
                        // taken by the concurrent can_see sweep; 29+ costs a second wave generation)
@@ -456,6 +457,7 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.farslot = c->d_farslot.p;
     B.force = c->d_force.p;
     B.cand = c->d_cand.p;
+    B.gallop = c->d_gallop.p;
     B.dbg = c->d_dbg;
     return B;
 }
@@ -471,7 +473,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans) {
     const int band_blocks = c->band_blocks;
     const uint32_t tot2 = 2u * c->tot;
     const LoopBufs B = loop_bufs(c);
-    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K,
+    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
                        (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW);
@@ -1158,6 +1160,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
     if (const char* s = getenv("SW_ELECT_IMPL")) c->elect_impl = atoi(s);
+    if (const char* s = getenv("SW_GALLOP")) c->gallop_after = std::max(0, atoi(s));
     c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
     if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
         if (hipMalloc(&c->d_dbg, (size_t)SW_DBG_MAX_ITERS * 32 * 8) != hipSuccess) c->d_dbg = nullptr;
@@ -1215,6 +1218,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_farslot, 2 * np, 0));
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
     CCHK(dgrow(c, c->d_cand, (size_t)2 * np * 64, 0));
+    CCHK(dgrow(c, c->d_gallop, 2 * np, 0));
     CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_chain_start, np, 0));
@@ -1265,7 +1269,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
-    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_Mb);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
