@@ -302,7 +302,7 @@ def bulk_rounds_v2(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None):
     return L, np.array(lo, np.int64).astype(np.int32), stats
 
 
-def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_after=2):
+def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_after=2, skip=0):
     """bulk_rounds_v2 plus GALLOPING for long runs of false candidates (a few members creating
     most of the events: thousands of chain positions per round, K per iteration).  After
     `gallop_after` consecutive windows without a passing candidate a member's window becomes
@@ -310,6 +310,10 @@ def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_
     failing slot rules out everything before it, and a passing slot f > 0 brackets the first
     passing position in (slot f-1, slot f], which one ordinary window covers.  A strided window
     falls back to an ordinary one whenever it meets a far candidate or the end of the chain.
+    `skip` > 0 additionally starts the window of a fresh round `skip` positions after the cursor
+    (the first positions after a witness practically never pass): a passing slot 0 then brackets
+    the first passing position in [cursor, cursor + skip] and the member looks again from the
+    cursor; so does a far slot 0.
     Prototype of the next kernel change; the rest is bulk_rounds_v2:
     Round loop with the inheritance shortcut for FAR candidates (kernel structure of
     k_resolve_band / k_tally_* since the slow-member fix):
@@ -345,6 +349,12 @@ def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_
         cur = pos.copy()
         stride = np.ones(n, np.int64)
         misses = np.zeros(n, np.int64)
+        skipped = np.zeros(n, np.int64)   # positions [cur - skipped, cur) have not been looked at
+        if skip:
+            for c in range(n):
+                if active[c] and cur[c] + skip < len(chains[c]):
+                    cur[c] += skip
+                    skipped[c] = skip
         mhi_done = mlo
         masks = {}
         while not resolved.all():
@@ -391,6 +401,14 @@ def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_
             for c in unres:
                 f, jf = found[c], farslot[c]
                 s_ = int(stride[c])
+                if skipped[c]:
+                    if (f == 0 and (jf is None or jf > 0)) or jf == 0:
+                        cur[c] -= skipped[c]           # slot 0 passed or is far: look again from the cursor
+                        skipped[c] = 0
+                        refined.add(c)
+                        stats["refines"] += 1
+                        continue
+                    skipped[c] = 0                     # slot 0 failed: everything before it fails too
                 if f is not None and (jf is None or f < jf):
                     if s_ == 1 or f == 0:
                         newly[c] = (int(chains[c][cur[c] + f * s_]), cur[c] + f * s_)

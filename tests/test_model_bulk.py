@@ -101,3 +101,23 @@ def test_galloping_window_model(pkg, n, N, seed, mode, p0, p1, K, cap):
         assert 2 * st3["iters"] < st2["iters"] and 2 * st3["evals"] < st2["evals"]
     else:       # elsewhere galloping must not cost more than a few percent
         assert st3["iters"] <= st2["iters"] * 1.1 + 2
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,K,cap", [
+    (12, 4000, 33, 0, 0, 0, 6, 48), (24, 5000, 40, 0, 0, 0, 10, 200), (20, 5000, 41, 3, 0.6, 0, 8, 100),
+    (24, 4000, 7, 2, 0.2, 0.002, 8, 64), (16, 6000, 31, 2, 0.2, 50.0, 4, 64),
+])
+@pytest.mark.parametrize("skip", [1, 2, 3])
+def test_window_offset_model(pkg, n, N, seed, mode, p0, p1, K, cap, skip):
+    """Next kernel change, validated here first: the window of a fresh round
+    starts `skip` positions after the cursor (at 256 members the first passing position is
+    13.8 +- 3.7 after it, never before position 1), a passing or far slot 0 sends the member back
+    to the cursor.  Exactness vs the oracle, with far candidates, waits and galloping in play."""
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    o = Oracle(n)
+    o.append_events(cr, sp, op, t, sig)
+    o.divide_rounds(0, N)
+    L3, lo3, st3 = mb.bulk_rounds_v3(n, cr, sp, op, np.ones(n, np.int64), K=K, NEARCAP=cap, skip=skip)
+    rnd, S, wit = mb.finalize(n, cr, L3, lo3)
+    assert np.array_equal(rnd, o.round)
+    assert np.array_equal(wit, o.witnesses())
