@@ -1,13 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — events/sec through divide_rounds + decide_fame (BASELINE.json metric).
 
-One "step" = one pass of the hot path (sw_divide_rounds + sw_decide_fame through the
-C-ABI) over one synthetic hashgraph whose events are ALREADY resident in HBM
-(sw_append_events is ingest, mirrors Node.add_event, and is outside the timed region).
+One "step" = sw_rewind + sw_divide_rounds + sw_decide_fame through the C-ABI over one synthetic
+hashgraph whose events are ALREADY resident in HBM (sw_append_events is ingest, mirrors
+Node.add_event, outside the timed region of `value`; `value_end_to_end` includes it, see below).
 Workload at N=1: BASELINE.json configs[2] — 256 members, 1M events, uniform gossip
-(SURVEY.md §8d generator), seed 3.  With --gpus N every rank runs an independent replica
-of that workload (different seed): the path does not shard across GPUs (DESIGN.md §(e),
-"replicas only"), so scaling is weak and there is no data-path collective.
+(SURVEY.md §8d generator), seed 3.
+
+--gpus N runs N INDEPENDENT replicas of that workload (one hashgraph per GPU, different seeds):
+`"scaling": "weak-replicas"`.  This is NOT the strong-scaling split north_star asks for (one 1M-event
+DAG over 8 GPUs, >= 6x): DESIGN.md §8 explains why the path is latency-bound and what the partitioned
+prototype (py-swirld_amd/partition.py, gloo-tested) would cost; no data-path collective runs here.
+
+Extra fields of the JSON line:
+  value_end_to_end  events/s from "SoA arrays in host memory" to "round[N], witness table, famous,
+                    new_c back in host memory" (SURVEY.md §8d Timing): sw_reset + sw_append_events +
+                    sw_divide_rounds + sw_decide_fame + getters, on a context whose device storage is
+                    already allocated.  PCIe-inclusive; never `value`.
+  roofline          the kernel with the largest total time, plus a `kernels` table (every family of
+                    the path: algorithmic bytes per launch per SURVEY.md §8d, average launch duration
+                    measured live with hipEvents, counter-measured HBM bytes per launch from the
+                    same-commit rocprofv3 --pmc passes in profiles/traffic.json) and the whole-path
+                    algorithmic rate.
+  cpu_baseline      the C oracle (kind "port") on one host core over a bounded sample.
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +38,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 achievable
+
 
 def algorithmic_bytes(n, counters, n_events):
     """SURVEY.md §8(d): divide_rounds 12n + n^2/8 + 24 per non-root event;
@@ -30,6 +47,18 @@ def algorithmic_bytes(n, counters, n_events):
     dr = (n_events - n) * (12 * n + n * n // 8 + 24)
     df = counters["voter_evals"] * (4 * n + n * n // 8) + counters["majority_evals"] * (n // 8)
     return dr, df
+
+
+def load_traffic():
+    """profiles/traffic.json: HBM bytes per launch per kernel family from rocprofv3 --pmc passes
+    (FETCH_SIZE doubled + WRITE_SIZE, separate passes) — measured by profiles/collect_traffic.py
+    on the commit named inside; not measured by this run."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(tpath))
+        return t.get("kernels", {}), t.get("commit"), t.get("workload")
+    except Exception:
+        return {}, None, None
 
 
 def main():
@@ -46,6 +75,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="generator mode (0 uniform gossip = the benchmark; 1 cliques, 2 slow members, 3 stale other-parents: robustness runs)")
     ap.add_argument("--p0", type=float, default=0.0)
     ap.add_argument("--p1", type=float, default=0.0)
+    ap.add_argument("--e2e-steps", type=int, default=3, help="end-to-end passes (host arrays in, results on host); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -68,18 +98,16 @@ def main():
     for _ in range(n_ctx):
         h = pkg.Hashgraph(n, device=local_rank)
         h.reserve(N)
-        h.append_events(*stream)  # ingest (Node.add_event): untimed
+        h.append_events(*stream)  # ingest (Node.add_event): outside the timed region of `value`
         ctxs.append(h)
     ingest_s = (time.perf_counter() - t_ing0) / n_ctx
-    for h in ctxs:  # set-up: every resident context builds its launch graphs once, then forgets the results
+    for h in ctxs:  # set-up: every resident context builds its launch graphs once
         h.divide_rounds(0, N)
         h.decide_fame()
-        h.rewind()
 
     def one_step(i):
         h = ctxs[i % n_ctx]
-        if i >= n_ctx:
-            h.rewind()  # inside the timed bracket when a context is reused
+        h.rewind()  # ALWAYS inside the timed bracket: every step starts from "events ingested, nothing divided"
         h.divide_rounds(0, N)
         return h.decide_fame()
 
@@ -98,13 +126,36 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * N * args.steps / dt
 
-    # ---- roofline of the dominant kernel (k_tally_candidates), one extra profiled pass ----
+    # ---- end to end: host SoA in -> round[N], witness table, famous, new_c on the host ----
+    e2e = None
+    if args.e2e_steps > 0:
+        h = ctxs[-1]
+
+        def e2e_step():
+            h.reset()                      # forget the events too (device storage stays allocated)
+            h.append_events(*stream)
+            h.divide_rounds(0, N)
+            nc = h.decide_fame()
+            return h.rounds(), h.witnesses(), h.famous(), nc
+
+        e2e_step()  # warm-up
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.e2e_steps):
+            r_e2e = e2e_step()
+        barrier()
+        dt_e2e = rep.max_over_ranks(time.perf_counter() - t1) / args.e2e_steps
+        e2e = {"events_per_s": round(world * N / dt_e2e, 1), "ms_per_pass": round(dt_e2e * 1e3, 3),
+               "includes": "sw_reset + sw_append_events (93 B/event over PCIe: parents, t, 64-byte signature) + "
+                           "sw_divide_rounds + sw_decide_fame + round[N] / witness table / famous read-back"}
+        assert len(r_e2e[0]) == N and list(r_e2e[3]) == list(new_c)
+
+    # ---- per-kernel roofline table: one extra profiled pass (plain launches, hipEvent pairs) ----
     h = ctxs[0]
     h.rewind()
     h.set_profiling(True)
     c0 = h.counters()
     h.divide_rounds(0, N)
-    tm_dr = h.timings()
     new_c_prof = h.decide_fame()
     tm = h.timings()
     c1 = h.counters()
@@ -112,32 +163,53 @@ def main():
     t_fo = time.perf_counter()
     ordered = h.find_order(new_c_prof)   # N1 (outside the metric): reported for information only
     find_order_ms = (time.perf_counter() - t_fo) * 1e3
-    cdelta = {k: c1[k] - c0[k] for k in c1}
-    cdelta_far = cdelta.get("far_hops", 0)
-    evals = c1["tally_evals"] - c0["tally_evals"]
-    launches = max(1, tm_dr["tally_launches"])
-    bytes_per_eval = 4 * n + n * n // 8 + 8  # one can_see row + n gathered n-bit masks + result
-    avg_launch_ms = tm_dr["tally_ms"] / launches
-    achieved = (evals / launches) * bytes_per_eval / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("tally_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    dr_b, df_b = algorithmic_bytes(n, cdelta, N)
+    cd = {k: c1[k] - c0[k] for k in c1}
+    traffic, traffic_commit, traffic_workload = load_traffic()
+
+    def fam(name, launches, total_ms, alg_bytes_total, served_by, note=None):
+        launches = max(1, int(launches))
+        avg_ms = total_ms / launches
+        ach = alg_bytes_total / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        d = {"kernel": name, "launches": launches, "avg_launch_us": round(avg_ms * 1e3, 2),
+             "total_ms": round(total_ms, 3), "alg_bytes_per_launch": int(alg_bytes_total / launches),
+             "achieved_GBps": round(ach, 1), "frac": round(ach / PEAK_GBPS, 5),
+             "hbm_bytes_per_launch_pmc": traffic.get(name), "served_by": served_by}
+        if note:
+            d["note"] = note
+        return d
+
+    npad = ((n + 63) // 64) * 64
+    cs_name = "k_cansee_member1b" if npad <= 256 else "k_cansee_stream"
+    kernels = [
+        fam(cs_name, tm["cansee_launches"], tm["cansee_kernel_ms"], 12 * n * (N - n), "hbm",
+            "12n B per event (2 parent rows read, 1 written); bound by the %d-level dependency chain" % cd["levels"]),
+        fam("k_resolve_band", tm["resolve_launches"], tm["resolve_ms"], cd["band_events"] * (4 * n + n // 8), "hbm/L2",
+            "4n B read + n/8 B written per band event; the replicated resolve step (latency) dominates its time"),
+        fam("k_tally_bits", tm["tally_launches"], tm["tally_ms"], cd["tally_evals"] * (4 * n + n * n // 8 + 8), "L2",
+            "one can_see row + n gathered n-bit masks per evaluation; the gathers hit the L2-resident band table, "
+            "so the rate is an L2-gather rate, not HBM"),
+        fam("k_elections", 1, tm["elections_ms"], cd["majority_evals"] * (n // 8), "L2/LDS"),
+    ]
+    dom = max(kernels, key=lambda k: k["total_ms"])
+    dr_b, df_b = algorithmic_bytes(n, cd, N)
+    path_gbps = (dr_b + df_b) / (ms_per_step * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": "k_tally_bits", "achieved": round(achieved, 2), "peak": 8000.0,
-        "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-        "avg_launch_us": round(avg_launch_ms * 1e3, 2), "launches": launches,
-        "evals_per_launch": round(evals / launches, 1), "bytes_per_eval": bytes_per_eval,
-        "far_hops": cdelta_far,
-        "path_algorithmic_GBps": round((dr_b + df_b) / (ms_per_step * 1e-3) / 1e9, 2),
-        "phase_ms": {k: round(v, 3) for k, v in (("can_see", tm_dr["can_see_ms"]), ("rounds", tm_dr["rounds_ms"]),
-                                                 ("tally", tm_dr["tally_ms"]), ("aux_finalize_voter_span", tm_dr["finalize_ms"]),
-                                                 ("fame", tm["fame_ms"]))},
-        "phase_note": "can_see and aux spans run on their own streams and overlap the round loop",
+        "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": PEAK_GBPS,
+        "unit": "GB/s", "frac": dom["frac"], "traffic": dom["hbm_bytes_per_launch_pmc"],
+        "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, commit %s, %s); "
+                          "not measured by this run" % (traffic_commit, traffic_workload),
+        "avg_launch_us": dom["avg_launch_us"], "launches": dom["launches"],
+        "dominant_by": "largest total kernel time of the profiled pass",
+        "kernels": kernels,
+        "path_algorithmic_GBps": round(path_gbps, 2), "path_frac": round(path_gbps / PEAK_GBPS, 5),
+        "path_note": "whole-pass algorithmic bytes (SURVEY.md §8d) / ms_per_step: the path is bound by its dependency "
+                     "chains (DAG levels, rounds), not by bandwidth",
+        "counters": {k: cd[k] for k in ("levels", "round_iterations", "tally_evals", "band_events", "voter_evals",
+                                        "majority_evals", "far_hops")},
+        "phase_ms": {k: round(v, 3) for k, v in (("can_see_stream_span", tm["can_see_ms"]), ("round_loop_span", tm["rounds_ms"]),
+                                                 ("aux_finalize_voter_span", tm["finalize_ms"]), ("fame", tm["fame_ms"]))},
+        "phase_note": "profiled pass = plain launches with event pairs (slower than the graph-replayed timed steps); "
+                      "can_see and aux spans run on their own streams and overlap the round loop",
     }
 
     # ---- CPU baseline: the oracle (C port of the reference algorithm), 1 core, bounded sample ----
@@ -154,19 +226,24 @@ def main():
         cpu_baseline = {"value": round(M / tc, 1), "unit": "events/s", "cores": 1, "kind": "port",
                         "host_cores": os.cpu_count(),
                         "sample": "first %d events of the same stream through oracle/swirld_oracle.c "
-                                  "(sequential C restatement of swirld.py:187-277), %.1f s" % (M, tc)}
+                                  "(sequential C restatement of swirld.py:187-277), %.1f s" % (M, tc),
+                        "python_reference_note": "the unmodified pure-Python reference cannot travel to the GPU box; in the "
+                                                 "authoring container it runs 204 events/s at 256 members (BASELINE.md §3)"}
 
     if rank == 0:
         out = {
             "metric": "events/sec through divide_rounds+decide_fame", "value": round(value, 1),
             "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak" if world == 1 else "weak-replicas",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "value_end_to_end": e2e["events_per_s"] if e2e else None,
+            "end_to_end": e2e,
             "config": {"workload": "%d members, %d events, %s hashgraph, one batch "
                                    "divide_rounds + decide_fame per step" % (
                                        n, N, ["uniform-gossip", "two-clique", "slow-member", "stale-other-parent"][args.mode]),
                        "members": n, "events": N, "seed": args.seed,
-                       "parallelism": "replicas x%d (no data-path collective)" % world,
+                       "parallelism": "replicas x%d (no data-path collective; strong-scaling target of north_star unmet)" % world,
                        "rounds": c1["rounds"], "ingest_s_untimed": round(ingest_s, 3),
                        "new_c_last_step": int(len(new_c)),
                        "find_order_ms_untimed": round(find_order_ms, 2), "events_ordered": int(len(ordered))},

@@ -67,9 +67,11 @@ int sw_reserve(sw_ctx* ctx, int64_t n_events);
  * of swirld.py:281-285).  t and sig64 may be NULL (zeros are stored).
  * Validation mirrors is_valid_event's structural half (swirld.py:104-108): parents
  * must exist, self-parent must be by the same creator, other-parent by another.
- * A fork (two children of one self-parent, or a second root of one member) is
- * accepted and recorded; the round-synchronous bulk path then refuses it
- * (SW_ENOTSUP, fork behaviour is unspecified in the reference, README.md:84).
+ * A fork (an event whose self-parent is not its creator's latest event, or a second
+ * root of one member) is refused with SW_ENOTSUP and NOTHING of the call is stored:
+ * the round-synchronous path needs one self-parent chain per member (the reference
+ * has no fork detection and leaves fork behaviour unspecified, README.md:84; the
+ * drop-in Node drops forked events in is_valid_event so that it keeps running).
  */
 int sw_append_events(sw_ctx* ctx, int64_t K, const int32_t* creator, const int32_t* self_parent,
                      const int32_t* other_parent, const double* t, const uint8_t* sig64);
@@ -134,6 +136,7 @@ typedef struct sw_counters {
     int64_t levels;              /* DAG height levels swept by the can_see kernel          */
     int64_t kernel_launches;
     int64_t far_hops;            /* hop masks rebuilt from rows because the hop lay outside the band */
+    int64_t band_events;         /* band events whose threshold mask was built by the round loop      */
 } sw_counters;
 int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 
@@ -148,6 +151,12 @@ typedef struct sw_timings {
                              /* rows, voter masks per sub-batch (overlaps the round loop)    */
     float fame_ms;           /* decide_fame: voter tallies + elections                   */
     float total_ms;
+    /* per kernel family (hipEvent pairs around each launch, so dispatch gaps are included) */
+    float cansee_kernel_ms;  /* sum over the can_see sweep launches                       */
+    int32_t cansee_launches;
+    float resolve_ms;        /* sum over the k_resolve_band launches that did work         */
+    int32_t resolve_launches;
+    float elections_ms;      /* the elections kernel of the most recent decide_fame        */
 } sw_timings;
 int sw_set_profiling(sw_ctx* ctx, int enable);
 int sw_get_timings(sw_ctx* ctx, sw_timings* out);
@@ -160,6 +169,9 @@ int sw_debug_clocks(sw_ctx* ctx, unsigned long long* out, int64_t cap_words);
  * witnesses, fame, consensus, order) as if divide_rounds had never been called; the
  * appended events stay resident.  Lets bench.py time repeated passes over one DAG. */
 int sw_rewind(sw_ctx* ctx);
+/* Measurement utility: sw_rewind + forget the appended events as well; device storage stays
+ * allocated.  Lets bench.py time repeated end-to-end passes (ingest included) on one context. */
+int sw_reset(sw_ctx* ctx);
 
 /* Block until all work queued on the context's stream is complete. */
 int sw_synchronize(sw_ctx* ctx);

@@ -22,13 +22,14 @@ class SwirldHipError(RuntimeError):
 class Counters(C.Structure):
     _fields_ = [(k, C.c_int64) for k in (
         "events_divided", "rounds", "tally_evals", "round_iterations", "voter_evals",
-        "majority_evals", "levels", "kernel_launches", "far_hops")]
+        "majority_evals", "levels", "kernel_launches", "far_hops", "band_events")]
 
 
 class Timings(C.Structure):
     _fields_ = [("can_see_ms", C.c_float), ("rounds_ms", C.c_float), ("tally_ms", C.c_float),
                 ("tally_launches", C.c_int32), ("finalize_ms", C.c_float), ("fame_ms", C.c_float),
-                ("total_ms", C.c_float)]
+                ("total_ms", C.c_float), ("cansee_kernel_ms", C.c_float), ("cansee_launches", C.c_int32),
+                ("resolve_ms", C.c_float), ("resolve_launches", C.c_int32), ("elections_ms", C.c_float)]
 
 
 # name -> (restype, argtypes): every symbol include/swirld_hip.h declares
@@ -60,6 +61,7 @@ SIGNATURES = {
     "sw_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "sw_debug_clocks": (C.c_int, [_P, _P, C.c_int64]),
     "sw_rewind": (C.c_int, [_P]),
+    "sw_reset": (C.c_int, [_P]),
     "sw_synchronize": (C.c_int, [_P]),
     "sw_synth_hashgraph": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_double,
                                      C.c_double, _P, _P, _P, _P, _P]),

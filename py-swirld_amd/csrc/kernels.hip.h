@@ -32,6 +32,7 @@ struct RState {
     int err;        // 1 = lo table capacity exceeded
     u64 evals;      // tallies evaluated (live candidates)
     u64 far_hops;   // hop masks computed on the fly (outside the band)
+    u64 band_events;  // band events whose threshold mask was (re)built (work of k_resolve_band's step 2)
 };
 
 struct FameCounters {
@@ -1017,6 +1018,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARC
             t.ncap = ncap;
             t.iter = iter + 1; t.n_unres = nun;
             t.evals = si->evals + (u64)s_cnt;
+            t.band_events = si->band_events + (u64)((need_mask && !done) ? mhi - mask_from : 0);
             if (done) t.max_round = max_round;
             if (err) t.err = 1;
             *so = t;

@@ -257,17 +257,17 @@ hipEvent_t next_event(sw_ctx* c) {
 struct Span {
     hipEvent_t a = nullptr, b = nullptr;
 };
-Span span_begin(sw_ctx* c) {
+Span span_begin(sw_ctx* c, hipStream_t strm = nullptr) {
     Span s;
     if (c->profiling) {
         s.a = next_event(c);
         s.b = next_event(c);
-        if (s.a) (void)hipEventRecord(s.a, c->stream);
+        if (s.a) (void)hipEventRecord(s.a, strm ? strm : c->stream);
     }
     return s;
 }
-void span_end(sw_ctx* c, Span& s) {
-    if (c->profiling && s.b) (void)hipEventRecord(s.b, c->stream);
+void span_end(sw_ctx* c, Span& s, hipStream_t strm = nullptr) {
+    if (c->profiling && s.b) (void)hipEventRecord(s.b, strm ? strm : c->stream);
 }
 float span_ms(const Span& s) {
     float ms = 0.f;
@@ -466,17 +466,20 @@ LoopBufs loop_bufs(sw_ctx* c) {
 // device-side state, so extra iterations after `done` are no-ops.  `par` = iteration parity
 // (which half of the double-buffered loop state is read / written).
 template <int NW>
-void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans) {
+void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::vector<Span>* resolve_spans = nullptr) {
     const int np = c->npad, K = c->K;
     const int tally_blocks = np * K / 4;
     const int bt = std::max(np, 256);
     const int band_blocks = c->band_blocks;
     const uint32_t tot2 = 2u * c->tot;
     const LoopBufs B = loop_bufs(c);
+    Span sr{};
+    if (resolve_spans) sr = span_begin(c);
     hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
                        (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW);
+    if (resolve_spans) { span_end(c, sr); resolve_spans->push_back(sr); }
     Span s{};
     if (tally_spans) s = span_begin(c);
     if (c->unit_stake && c->tally_impl == 1)
@@ -504,9 +507,9 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans) {
 constexpr int kGraphSizes[3] = {24, 8, 2};
 
 template <int NW>
-int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans) {
+int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, std::vector<Span>* resolve_spans = nullptr) {
     if (!c->use_graph || tally_spans) {
-        for (int it = 0; it < n_iters; ++it) enqueue_iteration<NW>(c, it & 1, tally_spans);
+        for (int it = 0; it < n_iters; ++it) enqueue_iteration<NW>(c, it & 1, tally_spans, resolve_spans);
         return SW_OK;
     }
     sw_ctx::GraphKey key;
@@ -546,7 +549,7 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
                        (int)limit, c->NEARCAP);
     c->ctr.kernel_launches++;
-    std::vector<Span> tally_spans;
+    std::vector<Span> tally_spans, resolve_spans;
     RState st{};
     int launched = 0;
     // first shot: the predicted number of iterations for this many events (from the
@@ -563,7 +566,7 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     shot = std::min(shot, 4096) & ~1;
     for (;;) {
         CHK(ensure_rounds(c, c->R + launched + shot + 4));
-        CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr));
+        CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr, c->profiling ? &resolve_spans : nullptr));
         launched += shot;
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
@@ -595,7 +598,9 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         for (size_t i = 0; i < tally_spans.size() && (int)i < st.iter - 1; ++i) { ms += span_ms(tally_spans[i]); ++cnt; }
         *tally_ms_out += ms;
         *tally_launches_out += cnt;
+        for (size_t i = 0; i < resolve_spans.size() && (int)i < st.iter; ++i) { c->tm.resolve_ms += span_ms(resolve_spans[i]); c->tm.resolve_launches++; }
     }
+    c->ctr.band_events += (int64_t)st.band_events;
     return SW_OK;
 }
 
@@ -724,6 +729,8 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     hipStream_t cs = c->stream_cs;
     hipEvent_t cs_t0 = nullptr, cs_t1 = nullptr;
     if (c->profiling) { cs_t0 = next_event(c); cs_t1 = next_event(c); (void)hipEventRecord(cs_t0, cs); }
+    std::vector<Span> cansee_spans;
+    if (c->profiling) { c->tm.resolve_ms = 0.f; c->tm.resolve_launches = 0; }
     HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, cs));
     for (int i = 0; i < S; ++i) {
         const int64_t a = cut[i], k = cut[i + 1] - cut[i];
@@ -735,7 +742,10 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                            (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)a, (int)k, hmins[i],
                            (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
         c->ctr.kernel_launches += 3;
+        Span scs = span_begin(c, cs);
         CHK(launch_cansee<NW>(c, nlevs[i], i));
+        span_end(c, scs, cs);
+        if (c->profiling) cansee_spans.push_back(scs);
         HIPCHK(c, hipEventRecord(c->cs_events[i], cs));
     }
     if (c->profiling) (void)hipEventRecord(cs_t1, cs);
@@ -857,6 +867,9 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         c->tm.tally_launches = tally_launches;
         { float fm = 0.f; if (fin_t0 && fin_t1) (void)hipEventElapsedTime(&fm, fin_t0, fin_t1); c->tm.finalize_ms = fm; }  // aux stream span (overlaps)
         c->tm.total_ms = span_ms(sp_total);
+        c->tm.cansee_kernel_ms = 0.f;
+        c->tm.cansee_launches = (int32_t)cansee_spans.size();
+        for (const Span& s_ : cansee_spans) c->tm.cansee_kernel_ms += span_ms(s_);
     }
     return SW_OK;
 }
@@ -874,6 +887,7 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     c->sw_dirty_from = std::max(R, 1);
     HIPCHK(c, hipMemsetAsync(c->d_newc.p, 0, R, c->stream));
     bool split_done = false;
+    Span sp_el = span_begin(c);
     if constexpr (NW >= 2 && NW <= 4) {  // NW threads per candidate (see k_elections_split): npad * NW <= 1024
         if (R > max_c && c->elect_impl == 1) {
             if (c->unit_stake)
@@ -899,6 +913,7 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
                                tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
         c->ctr.kernel_launches++;
     }
+    span_end(c, sp_el);
     HIPCHK(c, hipGetLastError());
     std::vector<unsigned char> newc(R);
     FameCounters fc{};
@@ -917,7 +932,7 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     c->ctr.voter_evals += (int64_t)(fc.voter_evals - c->fc_seen.voter_evals);
     c->ctr.majority_evals += (int64_t)(fc.majority_evals - c->fc_seen.majority_evals);
     c->fc_seen = fc;
-    if (c->profiling) c->tm.fame_ms = span_ms(sp);
+    if (c->profiling) { c->tm.fame_ms = span_ms(sp); c->tm.elections_ms = span_ms(sp_el); }
     if (cnt > cap) return fail(c, SW_ERANGE, "new_rounds capacity %d < %d", cap, cnt);
     return SW_OK;
 }
@@ -1107,7 +1122,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
 // ====================================================================================
 extern "C" {
 
-int sw_version(void) { return 1; }
+int sw_version(void) { return 2; }
 
 const char* sw_last_error(const sw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1302,18 +1317,28 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     if (K < 0 || (K > 0 && (!creator || !self_parent || !other_parent))) return fail(c, SW_EINVAL, "NULL event arrays");
     if (K == 0) return SW_OK;
     if (c->N + K > 0x7ffffff0ll) return fail(c, SW_ERANGE, "more than 2^31 events");
-    // structural validation (swirld.py:104-108) before anything is stored
-    for (int64_t i = 0; i < K; ++i) {
-        const int64_t e = c->N + i;
-        const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
-        if (m < 0 || m >= c->n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
-        if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
-        if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
-        if (s >= 0) {
-            const int32_t cs = s < c->N ? c->cr[s] : creator[s - c->N];
-            const int32_t co = o < c->N ? c->cr[o] : creator[o - c->N];
-            if (cs != m) return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
-            if (co == m) return fail(c, SW_EINVAL, "event %lld: other-parent is by the same member", (long long)e);
+    // structural validation (swirld.py:104-108) before anything is stored.  A fork (an event whose
+    // self-parent is not its creator's latest event, or a second root) is refused HERE, with the
+    // context untouched: the round-synchronous path needs one self-parent chain per member, and a
+    // stored fork would make every later sw_divide_rounds fail (a liveness hole for Node.main).
+    {
+        std::vector<int32_t> head_tmp(c->head);
+        for (int64_t i = 0; i < K; ++i) {
+            const int64_t e = c->N + i;
+            const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
+            if (m < 0 || m >= c->n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
+            if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
+            if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
+            if (s >= 0) {
+                const int32_t cs = s < c->N ? c->cr[s] : creator[s - c->N];
+                const int32_t co = o < c->N ? c->cr[o] : creator[o - c->N];
+                if (cs != m) return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
+                if (co == m) return fail(c, SW_EINVAL, "event %lld: other-parent is by the same member", (long long)e);
+            }
+            if (head_tmp[m] != s)
+                return fail(c, SW_ENOTSUP, "event %lld is a fork (member %d already has %s): forked hashgraphs are outside the "
+                            "supported domain; nothing was stored", (long long)e, m, s < 0 ? "a root" : "a later event on that self-parent");
+            head_tmp[m] = (int32_t)e;
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
@@ -1423,6 +1448,25 @@ int sw_rewind(sw_ctx* c) {
     c->sw_dirty_from = 1;
     c->transactions.clear();
     std::fill(c->ord_pos.begin(), c->ord_pos.end(), 0);
+    return SW_OK;
+}
+
+int sw_reset(sw_ctx* c) {
+    if (!c) return SW_EINVAL;
+    CHK(sw_rewind(c));
+    // forget the events as well; device storage (and the launch graphs keyed on it) stays
+    c->cr.clear(); c->sp.clear(); c->op.clear(); c->ht.clear();
+    std::fill(c->head.begin(), c->head.end(), -1);
+    std::fill(c->first_ev.begin(), c->first_ev.end(), -1);
+    std::fill(c->nev.begin(), c->nev.end(), 0);
+    c->appends.clear();
+    c->blk_hmin.clear(); c->blk_hmax.clear();
+    c->has_forks = false;
+    c->max_height = 0;
+    c->N = 0;
+    c->sig_h.clear();
+    c->chain_cap.clear();
+    c->pool_used = 0;
     return SW_OK;
 }
 

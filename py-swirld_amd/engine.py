@@ -153,7 +153,7 @@ class Hashgraph:
     def timings(self):
         t = Timings()
         self._chk(self._L.sw_get_timings(self._h, C.byref(t)))
-        return {k: (int(getattr(t, k)) if k == "tally_launches" else float(getattr(t, k)))
+        return {k: (int(getattr(t, k)) if k.endswith("_launches") else float(getattr(t, k)))
                 for k, _ in Timings._fields_}
 
     def debug_clocks(self):
@@ -165,6 +165,10 @@ class Hashgraph:
     def rewind(self):
         """Forget all voting state; the ingested events stay resident (bench utility)."""
         self._chk(self._L.sw_rewind(self._h))
+
+    def reset(self):
+        """rewind() and forget the events too; device storage stays allocated (bench utility)."""
+        self._chk(self._L.sw_reset(self._h))
 
     def synchronize(self):
         self._chk(self._L.sw_synchronize(self._h))

@@ -216,6 +216,7 @@ class Node:
         self._mindex = {pk: i for i, pk in enumerate(self._members)}
         self._ids = []
         self._index = {}
+        self._chain_head = {}  # {member pk -> its newest event in this view} (fork rejection)
         self._pending = []    # (creator, self_parent, other_parent, t, sig) not yet uploaded
         self._uploaded = 0
         self._divided = 0
@@ -262,13 +263,25 @@ class Node:
         mine, theirs = (self.hg[p].c for p in ev.p)
         return mine == ev.c and theirs != ev.c
 
+    def _not_a_fork(self, h, ev):
+        """DEVIATION from the reference (which has no fork detection, swirld.py:88-89, 110-112,
+        README.md:84): an event whose self-parent is not its creator's newest event in this view
+        (or a second root) is rejected, and with it everything built on top of it.  The device path
+        needs one self-parent chain per member; dropping the fork keeps an honest node running
+        where storing it would make every later divide_rounds fail."""
+        if h in self.hg:  # already accepted (sync re-validates the remote head, swirld.py:138)
+            return True
+        return self._chain_head.get(ev.c) == (ev.p[0] if ev.p else None)
+
     def is_valid_event(self, h, ev):
         """Signature, hash and parent checks (swirld.py:97-108)."""
-        return self._signature_ok(ev) and crypto.generichash(dumps(ev)) == h and self._parents_ok(ev)
+        return (self._signature_ok(ev) and crypto.generichash(dumps(ev)) == h and self._parents_ok(ev)
+                and self._not_a_fork(h, ev))
 
     def add_event(self, h, ev):
         """Store an event (swirld.py:114-120); it is uploaded with the next divide_rounds."""
         self.hg[h] = ev
+        self._chain_head[ev.c] = h
         self.tbd.add(h)
         self.height[h] = 1 + max(self.height[p] for p in ev.p) if ev.p else 0
         self._index[h] = len(self._ids)

@@ -15,6 +15,45 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "heavy: GPU parity case whose CPU oracle run takes about a minute "
+                                       "(computed in a background thread, see tests/oracle_pool.py)")
+
+
+_POOL = None
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_collection_modifyitems(config, items):
+    # heavy cases last: their oracle runs overlap everything that comes before them
+    items.sort(key=lambda it: 1 if it.get_closest_marker("heavy") else 0)
+
+
+def pytest_collection_finish(session):
+    global _POOL
+    names = []
+    for it in session.items:
+        mk = it.get_closest_marker("heavy")
+        if mk is not None:
+            names.extend(a for a in mk.args if a not in names)
+    if names and _POOL is None and not session.config.option.collectonly:
+        from oracle_pool import OraclePool
+        _POOL = OraclePool(names)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    global _POOL
+    if _POOL is not None:
+        _POOL.shutdown()
+        _POOL = None
+
+
+@pytest.fixture(scope="session")
+def oracle_pool():
+    global _POOL
+    if _POOL is None:
+        from oracle_pool import OraclePool
+        _POOL = OraclePool([])
+    return _POOL
 
 
 def golden_names():

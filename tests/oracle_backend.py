@@ -46,5 +46,11 @@ class OracleHashgraph:
     def famous(self, r0=0, r1=None):
         return self._o.famous_table(r0, r1)
 
+    def consensus(self, r0=0, r1=None):
+        return self._o.consensus(r0, r1)
+
+    def counters(self):
+        return self._o.counters()
+
     def close(self):
         pass

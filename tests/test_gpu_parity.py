@@ -83,10 +83,24 @@ def test_votes_match_reference(pkg, name):
 def test_fork_is_refused(pkg):
     g = load_golden("n8_s11_forks")
     h = pkg.Hashgraph(g["n"])
-    h.append_events(g["creator"], g["self_parent"], g["other_parent"], g["t"], g["sig"])
+    cr, sp, op = g["creator"], g["self_parent"], g["other_parent"]
     with pytest.raises(pkg.SwirldHipError) as ei:
-        h.divide_rounds(0, len(g["creator"]))
+        h.append_events(cr, sp, op, g["t"], g["sig"])
     assert ei.value.code == -95
+    assert h.num_events == 0, "a refused append stores nothing"
+    # the fork-free prefix is accepted and processed; the context stays usable afterwards
+    head, k = {}, 0
+    while k < len(cr) and head.get(int(cr[k]), -1) == sp[k]:
+        head[int(cr[k])] = k
+        k += 1
+    assert 0 < k < len(cr)
+    h.append_events(cr[:k], sp[:k], op[:k], g["t"][:k], g["sig"][:k])
+    h.divide_rounds(0, k)
+    with pytest.raises(pkg.SwirldHipError):
+        h.append_events(cr[k:k + 1], sp[k:k + 1], op[k:k + 1])
+    assert h.num_events == k
+    h.decide_fame()
+    assert np.array_equal(h.rounds(), g["round"][:k])
 
 
 def oracle_run(n, stream, stake=None, chunk=None):

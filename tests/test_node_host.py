@@ -70,3 +70,35 @@ def test_divide_rounds_rejects_out_of_order(pkg, monkeypatch):
         a.divide_rounds((b"x" * 32,))
     a.divide_rounds((hb, h2))
     assert a.round[h2] == 0 and a.witnesses[0][kp2[0]] == hb
+
+
+def test_forked_events_are_dropped_not_stored(pkg, monkeypatch):
+    """A Byzantine member signs two events on the same self-parent (a fork).  The reference
+    stores both (no fork detection); this Node accepts the first and drops the second and
+    everything built on it, so that the device path (one self-parent chain per member) keeps
+    running — and malformed signatures are rejected, not raised."""
+    monkeypatch.setattr(pkg.node, "Hashgraph", oracle_backend.OracleHashgraph)
+    crypto = pkg.node.crypto
+    kpa, kpb = crypto.sign_keypair(), crypto.sign_keypair()
+    stake = {kpa[0]: 1, kpb[0]: 1}
+    a = pkg.Node(kpa, {}, 2, stake)
+    b = pkg.Node(kpb, {}, 2, stake)
+    ra, rb = a.head, b.head
+    b.add_event(ra, a.hg[ra])
+    a.add_event(rb, b.hg[rb])
+    h1, e1 = b.new_event(b"one", (rb, ra))
+    h2, e2 = b.new_event(b"two", (rb, ra))      # same self-parent: a fork of member b
+    assert a.is_valid_event(h1, e1)
+    a.add_event(h1, e1)
+    assert not a.is_valid_event(h2, e2)         # the second child of rb is dropped
+    b.add_event(h2, e2)                         # (b itself builds on the fork)
+    h3, e3 = b.new_event(b"three", (h2, ra))
+    assert not a.is_valid_event(h3, e3)         # parent unknown to a: dropped as well
+    a.divide_rounds((rb, h1))
+    assert a.round[h1] == 0
+    # malformed signatures: rejected by is_valid_event instead of escaping as ctypes errors
+    assert not a.is_valid_event(h1, e1._replace(s=e1.s[:10]))
+    assert not a.is_valid_event(h1, e1._replace(s="not bytes"))
+    # a second root of a member is a fork too
+    hr, er = b.new_event(None, ())
+    assert not a.is_valid_event(hr, er)
