@@ -179,10 +179,11 @@ def main():
         return d
 
     npad = ((n + 63) // 64) * 64
-    cs_name = "k_cansee_member1b" if npad <= 256 else "k_cansee_stream"
+    cs_impl = int(os.environ.get("SW_CANSEE_IMPL", "6"))
+    cs_name = "k_cansee_flow" if cs_impl >= 6 else ("k_cansee_member1b" if npad <= 256 else "k_cansee_stream")
     kernels = [
         fam(cs_name, tm["cansee_launches"], tm["cansee_kernel_ms"], 12 * n * (N - n), "hbm",
-            "12n B per event (2 parent rows read, 1 written); bound by the %d-level dependency chain" % cd["levels"]),
+            "12n B per event (2 parent rows read, 1 written); bound by the dependency chain of the DAG (about 3.4 N/n levels)"),
         fam("k_resolve_band", tm["resolve_launches"], tm["resolve_ms"], cd["band_events"] * (4 * n + n // 8), "hbm/L2",
             "4n B read + n/8 B written per band event; the replicated resolve step (latency) dominates its time"),
         fam("k_tally_bits", tm["tally_launches"], tm["tally_ms"], cd["tally_evals"] * (4 * n + n * n // 8 + 8), "L2",

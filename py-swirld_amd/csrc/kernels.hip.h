@@ -620,6 +620,237 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
 }
 
 // ---------------------------------------------------------------------------------
+// Sixth version: DATAFLOW sweep — no DAG levels, no heights, no barriers.
+//
+// The level-synchronous kernels above pay one workgroup barrier (~0.45 us) per DAG level and
+// need the events bucketed by height first.  Here every member's self-parent chain is walked by
+// one lane at its own pace: the lane's next event needs (a) the member's previous row value,
+// which stays in a register, and (b) the other-parent's value, which the lane POLLS for in an LDS
+// ring of {event id, value} pairs (slot = chain position mod H, one 8-byte read).  A lane whose
+// dependency is not there yet simply tries again in the next trip of its wave's loop; lanes of
+// one wave progress independently (one loop, per-lane state), waves never wait for each other.
+//  * tag == wanted: hit.  tag < wanted: not produced yet (event ids grow along a chain): poll
+//    again.  tag > wanted: the slot was reused, i.e. the producer lane has advanced >= H
+//    positions since, each with its own store instruction, and every producer wave keeps at most
+//    6 store instructions in flight (`s_waitcnt vmcnt(6)` after each) — so the row reached L2
+//    long ago and is re-read from there with an sc1 load.  Events before `first_event` were
+//    written by earlier kernels and are read from memory directly.
+//  * Deadlock-free: a lane only waits for events with a smaller index, so the lowest unprocessed
+//    event of the sub-batch can always proceed; all waves of the workgroup are resident.
+//  * Descriptors {event, other-parent, creator(op) | seq(op) << 10} come per member from a
+//    pool-indexed array (same indexing as chain_ev), streamed by one LOADER wave into per-member
+//    LDS FIFOs (loads and stores share the in-order vmcnt counter of a wave, so workers only store
+//    and the loader only loads, as in the level kernels); `filled` / `taken` are per-member LDS
+//    counters, DS operations of one wave are processed in order, and every polled location is
+//    re-read behind a compiler barrier.
+//  * One workgroup per column (XCD-aware mapping as above), npad / MPL worker lanes each walking
+//    MPL chains + 64 loader lanes; 1024 members run as 512 lanes x 2 chains.
+// ---------------------------------------------------------------------------------
+#define SW_CBAR() asm volatile("" ::: "memory")
+
+// A load the compiler's wait-count pass does not see: issued and waited for inside one asm
+// statement.  A visible load inside the worker loop would make the pass put `s_waitcnt vmcnt(0)`
+// in front of every later use of the (reused) destination register, i.e. drain the wave's stores
+// on every trip.  sc1: served by L2, bypassing this CU's vector L1.
+__device__ __forceinline__ int load_sc1_and_wait(const int* ptr) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+template <int NW, int MPL, int F, int H>
+__global__ void __launch_bounds__(64 * NW / MPL + 64)
+k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_start,
+              const int* __restrict__ pos0, const int* __restrict__ pos1,
+              const int* __restrict__ chain_ev, int first_event, int* L, int* err) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr int npad = 64 * NW;
+    constexpr int NT = npad / MPL;       // worker lanes
+    constexpr int SPIN_LIMIT = 1 << 27;  // trips of a polling loop before it gives up (a protocol bug, never work)
+    constexpr int hm = H - 1, fm = F - 1;
+    static_assert((H & hm) == 0 && (F & fm) == 0 && H <= 64 && H >= 8, "ring / FIFO depths are powers of two; H > 6 store instructions");
+    int4* fifo = (int4*)smem;                                  // [F][npad]
+    u64* ring = (u64*)(fifo + (size_t)F * npad);               // [H][npad] {value << 32 | event id}
+    int* filled = (int*)(ring + (size_t)H * npad);             // [npad] chain positions loaded so far
+    int* taken = filled + npad;                                // [npad] chain positions taken by the worker
+    const int tid = threadIdx.x;
+    const bool loader = tid >= NT;
+    const int ll = tid - NT;              // loader lane
+    const int nblk = gridDim.x;
+    const int col = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
+    for (int i = tid; i < npad * H; i += blockDim.x) ring[i] = 0xffffffffffffffffull;  // id -1: empty
+    for (int i = tid; i < npad; i += blockDim.x) { const int p = pos0[i]; filled[i] = p; taken[i] = p; }
+    __syncthreads();
+    if (loader) {
+        // members ll, ll + 64, ...: refill a member's FIFO with B descriptors whenever B slots are free;
+        // G members per memory round trip (all their loads in flight together)
+        constexpr int B = F / 2;
+        constexpr int MAXBUF = NW >= 8 ? 16 : 32;  // descriptors staged in registers per round trip
+        constexpr int G = (NW * B <= MAXBUF) ? NW : MAXBUF / B;
+        static_assert(G >= 1 && NW % G == 0, "loader groups");
+        int fl[NW], pe[NW], cs[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int k = ll + 64 * j;
+            fl[j] = pos0[k];
+            pe[j] = pos1[k];
+            cs[j] = chain_start[k];
+        }
+        for (int spins = 0;; ++spins) {
+            bool more = false;
+            unsigned need = 0;
+            if (spins > SPIN_LIMIT) { if (ll == 0) atomicExch(err, 2); break; }
+            SW_CBAR();
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                if (fl[j] < pe[j]) {
+                    more = true;
+                    const int tk = taken[ll + 64 * j];
+                    if (fl[j] - tk <= F - B) need |= 1u << j;
+                }
+            }
+            if (!__ballot(more)) break;
+            if (!__ballot(need != 0)) { __builtin_amdgcn_s_sleep(2); continue; }
+#pragma unroll
+            for (int g0 = 0; g0 < NW; g0 += G) {
+                int bx[G * B], by[G * B], bz[G * B];  // (scalar arrays: promoted to registers after unrolling)
+#pragma unroll
+                for (int jj = 0; jj < G; ++jj) {
+                    const int j = g0 + jj;
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        bx[jj * B + u] = -1; by[jj * B + u] = -1; bz[jj * B + u] = 0;
+                        if (((need >> j) & 1u) && fl[j] + u < pe[j]) {
+                            const int4 t = cdesc[(size_t)cs[j] + fl[j] + u];
+                            bx[jj * B + u] = t.x; by[jj * B + u] = t.y; bz[jj * B + u] = t.z;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < G; ++jj) {
+                    const int j = g0 + jj;
+                    if ((need >> j) & 1u) {
+                        const int k = ll + 64 * j;
+                        int nf = fl[j];
+#pragma unroll
+                        for (int u = 0; u < B; ++u)
+                            if (fl[j] + u < pe[j]) {
+                                fifo[(size_t)((fl[j] + u) & fm) * npad + k] = make_int4(bx[jj * B + u], by[jj * B + u], bz[jj * B + u], 0);
+                                nf = fl[j] + u + 1;
+                            }
+                        SW_CBAR();  // the entries are written before the count that publishes them (DS ops stay in order)
+                        filled[k] = nf;
+                        SW_CBAR();
+                        fl[j] = nf;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- workers
+    int p[MPL], pend[MPL], mine[MPL];
+    int4 d[MPL];
+    bool have[MPL];
+#pragma unroll
+    for (int q = 0; q < MPL; ++q) {
+        const int m = tid + q * NT;
+        p[q] = pos0[m];
+        pend[q] = pos1[m];
+        mine[q] = -1;
+        have[q] = false;
+        d[q] = make_int4(-1, -1, 0, 0);
+        if (p[q] > 0 && p[q] < pend[q]) {  // the member's latest event of an earlier kernel: its row is the self-parent's row
+            const int prev = chain_ev[chain_start[m] + p[q] - 1];
+            mine[q] = L[(size_t)prev * npad + col];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MPL; ++q) asm volatile("" : "+v"(mine[q]));  // the prologue loads are complete before the loop
+    for (int spins = 0;; ++spins) {
+        bool busy = false, progressed = false;
+        if (spins > SPIN_LIMIT) { if ((tid & 63) == 0) atomicExch(err, 1); break; }
+        SW_CBAR();
+#pragma unroll
+        for (int q = 0; q < MPL; ++q) {
+            const int m = tid + q * NT;
+            if (!have[q] && p[q] < pend[q]) {
+                const int f = filled[m];
+                if (p[q] < f) {
+                    SW_CBAR();
+                    d[q] = fifo[(size_t)(p[q] & fm) * npad + m];
+                    SW_CBAR();
+                    taken[m] = p[q] + 1;  // the slot may be refilled from here on
+                    have[q] = true;
+                }
+            }
+            if (have[q]) {
+                int other = -1;
+                bool ready = true;
+                const int o = d[q].y;
+                if (o >= 0) {
+                    bool from_mem = o < first_event;
+                    if (!from_mem) {
+                        const int co = d[q].z & 1023, so = (d[q].z >> 10) & hm;
+                        const u64 pr = ring[(size_t)so * npad + co];
+                        const int tag = (int)(unsigned)pr;
+                        if (tag == o) other = (int)(pr >> 32);
+                        else if (tag > o) from_mem = true;   // slot reused: the row is >= H store instructions old
+                        else ready = false;                  // not produced yet
+                    }
+                    if (from_mem) other = load_sc1_and_wait(&L[(size_t)o * npad + col]);
+                }
+                if (ready) {
+                    const int e = d[q].x;
+                    int v = mine[q] > other ? mine[q] : other;  // maxi(): index order == height order on one chain
+                    if (col == m) v = e;                          // own entry (swirld.py:220)
+                    mine[q] = v;
+                    L[(size_t)e * npad + col] = v;
+                    ring[(size_t)(p[q] & hm) * npad + m] = ((u64)(unsigned)v << 32) | (unsigned)e;
+                    SW_CBAR();
+                    ++p[q];
+                    have[q] = false;
+                    progressed = true;
+                }
+            }
+            busy = busy || p[q] < pend[q];
+        }
+        // at most 6 store instructions of this wave in flight (see the reuse argument above)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (!__ballot(busy)) break;
+        if (!__ballot(progressed)) __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// chain positions of the sub-batch cuts: out[i][m] = number of member m's events with index < cut[i]
+__global__ void __launch_bounds__(1024)
+k_chain_bounds(const int* __restrict__ chain_start, const int* __restrict__ chain_cnt,
+               const int* __restrict__ chain_ev, const long long* __restrict__ cuts, int npad, int* out) {
+    const int m = threadIdx.x, i = blockIdx.x;
+    const int x = (int)cuts[i];
+    const int cs = chain_start[m];
+    int a = 0, b = chain_cnt[m];
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (chain_ev[cs + mid] < x) a = mid + 1; else b = mid;
+    }
+    out[(size_t)i * npad + m] = a;
+}
+
+// pool-indexed chain descriptors for the events [first, first + K): {event, other-parent,
+// creator(op) | (seq(op) & 63) << 10, self-parent}
+__global__ void k_chain_desc(const int* __restrict__ cr, const int* __restrict__ sp, const int* __restrict__ op,
+                             const int* __restrict__ seq, const int* __restrict__ chain_start, int first, int K, int4* cdesc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int e = first + i;
+    const int o = op[e];
+    int w = 0;
+    if (o >= 0) w = cr[o] | ((seq[o] & 63) << 10);
+    cdesc[(size_t)chain_start[cr[e]] + seq[e]] = make_int4(e, o, w, sp[e]);
+}
+
+// ---------------------------------------------------------------------------------
 // Round loop.  One iteration = k_resolve_band -> k_tally_*; ~1 iteration per round.
 // Round-synchronous form: round[e] >= r+1  <=>  SS_r(e), evaluated with the thresholds
 // lo[r][.] (checked on the CPU in tests/model_bulk.py).

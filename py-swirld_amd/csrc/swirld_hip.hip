@@ -61,6 +61,9 @@ struct sw_ctx {
     DBuf<int32_t> d_chain_start;  // npad: offset of each member's segment in the chain pool
     DBuf<int32_t> d_chain_cnt;    // npad: events per member (segments have slack: geometric growth)
     DBuf<int32_t> d_scat_idx, d_scat_val;
+    DBuf<int4> d_cdesc;           // pool-indexed chain descriptors of the dataflow can_see sweep (same indexing as chain_ev)
+    DBuf<int32_t> d_bounds;       // [cuts][npad] chain positions of the sub-batch cuts of the running divide_rounds call
+    DBuf<long long> d_cuts;
     std::vector<int32_t> chain_cap;   // per member: capacity of its segment
     int64_t pool_used = 0;             // ints of the chain pool handed out
     DBuf<int32_t> d_prev_head;    // 2 x npad (ping-pong): latest divided event per member (-1 none)
@@ -102,7 +105,7 @@ struct sw_ctx {
     int MCAP = 0;      // largest band (events) the mask table can hold
     int NEARCAP = 0;   // band cap at round entry (doubles up to MCAP when a far candidate needs a tally)
     int BATCH = 24;    // loop iterations between host checks
-    int cansee_impl = 5;  // 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
+    int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers; k_cansee_flow); 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
@@ -132,6 +135,7 @@ struct sw_ctx {
     DBuf<unsigned char> d_white;
     DBuf<double> d_ts;
     int* d_err = nullptr;
+    int* d_flow_err = nullptr;   // set by k_cansee_flow when a polling loop gives up (protocol bug)
 };
 
 namespace {
@@ -289,6 +293,17 @@ int upload_chain_index(sw_ctx* c) {
     return SW_OK;
 }
 
+// chain descriptors of the events [first, first + K) (needs cr/sp/op/seq/chain_start on the device)
+int build_chain_desc(sw_ctx* c, int64_t first, int64_t K) {
+    if (K <= 0) return SW_OK;
+    hipLaunchKernelGGL(k_chain_desc, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_cr.p,
+                       (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
+                       (int)first, (int)K, c->d_cdesc.p);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    return SW_OK;
+}
+
 int rebuild_chains(sw_ctx* c) {
     const int np = c->npad, n = c->n;
     std::vector<int32_t> cnt(n, 0);
@@ -312,7 +327,9 @@ int rebuild_chains(sw_ctx* c) {
     CHK(dgrow(c, c->d_chain_ev, (size_t)off + (size_t)off / 2 + 1024, 0));
     if (off)
         HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p, c->chain_ev_h.data(), (size_t)off * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    return upload_chain_index(c);
+    CHK(upload_chain_index(c));
+    CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, 0));
+    return build_chain_desc(c, 0, c->N);
 }
 
 // events [N0, N0 + K) were just stored: add them to their members' segments
@@ -332,9 +349,14 @@ int extend_chains(sw_ctx* c, int64_t N0, int64_t K) {
             std::copy(c->chain_ev_h.begin() + c->chain_start_h[m], c->chain_ev_h.begin() + c->chain_start_h[m] + filled[m],
                       c->chain_ev_h.begin() + noff);
             CHK(dgrow(c, c->d_chain_ev, (size_t)(noff + ncap) * 2, (size_t)c->pool_used));
-            if (filled[m])
+            CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, (size_t)c->pool_used));
+            if (filled[m]) {
                 HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p + noff, c->d_chain_ev.p + c->chain_start_h[m], (size_t)filled[m] * sizeof(int32_t),
                                          hipMemcpyDeviceToDevice, c->stream));
+                // (the descriptors of events appended earlier in this call are written below, after the move)
+                HIPCHK(c, hipMemcpyAsync(c->d_cdesc.p + noff, c->d_cdesc.p + c->chain_start_h[m], (size_t)filled[m] * sizeof(int4),
+                                         hipMemcpyDeviceToDevice, c->stream));
+            }
             // entries of this member appended earlier in this call are still pending in the scatter
             // list: re-target them to the new segment
             const int32_t old0 = c->chain_start_h[m], old1 = old0 + c->chain_cap[m];
@@ -356,7 +378,9 @@ int extend_chains(sw_ctx* c, int64_t N0, int64_t K) {
     hipLaunchKernelGGL(k_scatter_i32, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_scat_idx.p,
                        (const int*)c->d_scat_val.p, (int)K, c->d_chain_ev.p);
     c->ctr.kernel_launches++;
-    return upload_chain_index(c);
+    CHK(upload_chain_index(c));
+    CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, (size_t)c->pool_used));
+    return build_chain_desc(c, N0, K);
 }
 
 // geometry of the streaming can_see kernel for this member count
@@ -446,6 +470,33 @@ int launch_cansee(sw_ctx* c, int nlev, int pp) {
     c->ctr.kernel_launches++;
     HIPCHK(c, hipGetLastError());
     return SW_OK;
+}
+
+// dataflow can_see sweep of the sub-batch whose chain positions are bounds rows i and i + 1
+template <int NW, int MPL, int F, int H>
+int launch_cansee_flow_t(sw_ctx* c, int i, int64_t first_event) {
+    constexpr int npad = 64 * NW;
+    const size_t lds = (size_t)npad * ((size_t)F * 16 + (size_t)H * 8 + 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_cansee_flow<NW, MPL, F, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_cansee_flow<NW, MPL, F, H>), dim3(npad), dim3(npad / MPL + 64), lds, c->stream_cs,
+                       (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p,
+                       (const int*)c->d_bounds.p + (size_t)i * npad, (const int*)c->d_bounds.p + (size_t)(i + 1) * npad,
+                       (const int*)c->d_chain_ev.p, (int)first_event, c->d_L.p, c->d_flow_err);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    return SW_OK;
+}
+
+template <int NW>
+int launch_cansee_flow(sw_ctx* c, int i, int64_t first_event) {
+    if constexpr (NW <= 4) return launch_cansee_flow_t<NW, 1, 16, 32>(c, i, first_event);
+    else if constexpr (NW == 8) return launch_cansee_flow_t<8, 2, 8, 16>(c, i, first_event);   // 256 lanes x 2 chains
+    else return launch_cansee_flow_t<16, 4, 4, 8>(c, i, first_event);                          // 256 lanes x 4 chains
 }
 
 LoopBufs loop_bufs(sw_ctx* c) {
@@ -705,21 +756,24 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     }
     cut.push_back(first + K);
     const int S = (int)cut.size() - 1;
+    const bool flow = c->cansee_impl >= 6;
     std::vector<int> hmins(S), nlevs(S);
     int max_nlev = 1;
     int64_t max_k = 1;
-    for (int i = 0; i < S; ++i) {
-        int hmax;
-        height_span(c, cut[i], cut[i + 1], &hmins[i], &hmax);
-        nlevs[i] = hmax - hmins[i] + 1;
-        max_nlev = std::max(max_nlev, nlevs[i]);
-        max_k = std::max(max_k, cut[i + 1] - cut[i]);
-        c->ctr.levels += nlevs[i];
+    if (!flow) {
+        for (int i = 0; i < S; ++i) {
+            int hmax;
+            height_span(c, cut[i], cut[i + 1], &hmins[i], &hmax);
+            nlevs[i] = hmax - hmins[i] + 1;
+            max_nlev = std::max(max_nlev, nlevs[i]);
+            max_k = std::max(max_k, cut[i + 1] - cut[i]);
+            c->ctr.levels += nlevs[i];
+        }
+        CHK(dgrow(c, c->d_lev_cnt, max_nlev, 0));
+        CHK(dgrow(c, c->d_lev_start, max_nlev + 1, 0));
+        CHK(dgrow(c, c->d_lev_cursor, max_nlev, 0));
+        CHK(dgrow(c, c->d_desc, max_k, 0));
     }
-    CHK(dgrow(c, c->d_lev_cnt, max_nlev, 0));
-    CHK(dgrow(c, c->d_lev_start, max_nlev + 1, 0));
-    CHK(dgrow(c, c->d_lev_cursor, max_nlev, 0));
-    CHK(dgrow(c, c->d_desc, max_k, 0));
     while ((int)c->cs_events.size() < S) {
         hipEvent_t e;
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -731,19 +785,37 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     if (c->profiling) { cs_t0 = next_event(c); cs_t1 = next_event(c); (void)hipEventRecord(cs_t0, cs); }
     std::vector<Span> cansee_spans;
     if (c->profiling) { c->tm.resolve_ms = 0.f; c->tm.resolve_launches = 0; }
-    HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+    // chain positions of the cuts: bounds[i][m] = events of member m below cut[i] (device binary searches)
+    std::vector<int32_t> bounds_h((size_t)(S + 1) * np);
+    {
+        CHK(dgrow(c, c->d_cuts, S + 1, 0));
+        CHK(dgrow(c, c->d_bounds, (size_t)(S + 1) * np, 0));
+        std::vector<long long> cuts_ll(cut.begin(), cut.end());
+        HIPCHK(c, hipMemcpyAsync(c->d_cuts.p, cuts_ll.data(), (S + 1) * sizeof(long long), hipMemcpyHostToDevice, cs));
+        hipLaunchKernelGGL(k_chain_bounds, dim3(S + 1), dim3(np), 0, cs, (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p,
+                           (const int*)c->d_chain_ev.p, (const long long*)c->d_cuts.p, np, c->d_bounds.p);
+        c->ctr.kernel_launches++;
+        HIPCHK(c, hipMemcpyAsync(bounds_h.data(), c->d_bounds.p, bounds_h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, cs));
+    }
+    if (!flow) HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, cs));
     for (int i = 0; i < S; ++i) {
         const int64_t a = cut[i], k = cut[i + 1] - cut[i];
-        HIPCHK(c, hipMemsetAsync(c->d_lev_cnt.p, 0, nlevs[i] * sizeof(int32_t), cs));
-        const int eb = (int)((k + 255) / 256);
-        hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (int)a, (int)k, hmins[i], c->d_lev_cnt.p);
-        hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, cs, (const int*)c->d_lev_cnt.p, nlevs[i], c->d_lev_start.p, c->d_lev_cursor.p);
-        hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
-                           (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)a, (int)k, hmins[i],
-                           (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
-        c->ctr.kernel_launches += 3;
-        Span scs = span_begin(c, cs);
-        CHK(launch_cansee<NW>(c, nlevs[i], i));
+        Span scs{};
+        if (flow) {
+            scs = span_begin(c, cs);
+            CHK(launch_cansee_flow<NW>(c, i, a));
+        } else {
+            HIPCHK(c, hipMemsetAsync(c->d_lev_cnt.p, 0, nlevs[i] * sizeof(int32_t), cs));
+            const int eb = (int)((k + 255) / 256);
+            hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (int)a, (int)k, hmins[i], c->d_lev_cnt.p);
+            hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, cs, (const int*)c->d_lev_cnt.p, nlevs[i], c->d_lev_start.p, c->d_lev_cursor.p);
+            hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
+                               (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)a, (int)k, hmins[i],
+                               (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
+            c->ctr.kernel_launches += 3;
+            scs = span_begin(c, cs);
+            CHK(launch_cansee<NW>(c, nlevs[i], i));
+        }
         span_end(c, scs, cs);
         if (c->profiling) cansee_spans.push_back(scs);
         HIPCHK(c, hipEventRecord(c->cs_events[i], cs));
@@ -846,6 +918,11 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream_cs));
     HIPCHK(c, hipGetLastError());
+    if (flow) {
+        int ferr = 0;
+        HIPCHK(c, hipMemcpy(&ferr, c->d_flow_err, sizeof ferr, hipMemcpyDeviceToHost));
+        if (ferr) return fail(c, SW_EIO, "can_see sweep gave up polling (code %d): internal protocol error", ferr);
+    }
     clk.mark(&c->stage_us[5]);
     c->sw_dirty_from = std::max(R, 1);  // voter masks are up to date
     if (first + K == c->N) std::copy(c->head.begin(), c->head.end(), c->divided_head.begin());
@@ -1219,6 +1296,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
     CHIP(hipMemset(c->d_fc, 0, sizeof(FameCounters)));
     CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
+    CHIP(hipMalloc((void**)&c->d_flow_err, sizeof(int)));
+    CHIP(hipMemset(c->d_flow_err, 0, sizeof(int)));
     const int np = c->npad;
     CCHK(dgrow(c, c->d_stake, np, 0));
     CHIP(hipMemcpy(c->d_stake.p, c->stake_h.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1279,7 +1358,7 @@ int sw_destroy(sw_ctx* c) {
     }
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
-    dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_scat_idx); dfree(c->d_scat_val); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_scat_idx); dfree(c->d_scat_val); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
@@ -1288,6 +1367,7 @@ int sw_destroy(sw_ctx* c) {
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_flow_err) (void)hipFree(c->d_flow_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
     dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_acc_off); dfree(c->d_white);
     for (int g = 0; g < 3; ++g) {

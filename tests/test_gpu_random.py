@@ -21,7 +21,7 @@ def test_random_shapes(pkg, monkeypatch, seed):
     monkeypatch.setenv("SW_BAND", str(int(rng.choice([64, 256, 4096, 100000]))))
     if rng.random() < 0.5:
         monkeypatch.setenv("SW_BAND_MAX", str(int(rng.choice([64, 1024, 1 << 20]))))
-    monkeypatch.setenv("SW_CANSEE_IMPL", str(int(rng.choice([0, 1, 2, 3, 4, 5, 5, 5]))))
+    monkeypatch.setenv("SW_CANSEE_IMPL", str(int(rng.choice([0, 1, 2, 3, 4, 5, 5, 6, 6, 6]))))
     monkeypatch.setenv("SW_TALLY_IMPL", str(int(rng.choice([0, 1, 1]))))
     cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 9000 + seed, mode, p0, p1)
     t = t + rng.integers(0, 3, N) * 0.5
