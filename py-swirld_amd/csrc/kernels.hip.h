@@ -632,7 +632,7 @@ k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_sta
 //  * tag == wanted: hit.  tag < wanted: not produced yet (event ids grow along a chain): poll
 //    again.  tag > wanted: the slot was reused, i.e. the producer lane has advanced >= H
 //    positions since, each with its own store instruction, and every producer wave keeps at most
-//    6 store instructions in flight (`s_waitcnt vmcnt(6)` after each) — so the row reached L2
+//    H - 4 store instructions in flight (`s_waitcnt vmcnt(H - 4)` after each) — so the row reached L2
 //    long ago and is re-read from there with an sc1 load.  Events before `first_event` were
 //    written by earlier kernels and are read from memory directly.
 //  * Deadlock-free: a lane only waits for events with a smaller index, so the lowest unprocessed
@@ -658,11 +658,11 @@ __device__ __forceinline__ int load_sc1_and_wait(const int* ptr) {
     return v;
 }
 
-template <int NW, int MPL, int F, int H>
+template <int NW, int MPL, int F, int H, bool WIDE, bool DBG>
 __global__ void __launch_bounds__(64 * NW / MPL + 64)
 k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_start,
               const int* __restrict__ pos0, const int* __restrict__ pos1,
-              const int* __restrict__ chain_ev, int first_event, int* L, int* err) {
+              const int* __restrict__ chain_ev, int first_event, int* L, int* err, u64* dbg) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int npad = 64 * NW;
     constexpr int NT = npad / MPL;       // worker lanes
@@ -696,6 +696,7 @@ k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_star
             pe[j] = pos1[k];
             cs[j] = chain_start[k];
         }
+        int passes = 0, idle_passes = 0;
         for (int spins = 0;; ++spins) {
             bool more = false;
             unsigned need = 0;
@@ -710,20 +711,24 @@ k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_star
                 }
             }
             if (!__ballot(more)) break;
-            if (!__ballot(need != 0)) { __builtin_amdgcn_s_sleep(2); continue; }
+            if (!__ballot(need != 0)) { __builtin_amdgcn_s_sleep(2); ++idle_passes; continue; }
+            ++passes;
 #pragma unroll
             for (int g0 = 0; g0 < NW; g0 += G) {
+                // Branch-free loads with clamped positions: a load inside an exec-masked block makes
+                // the compiler wait for it at the end of the block, which serialised all loads of a pass
+                // (14 us per pass instead of one memory round trip).  Lanes that do not need a refill
+                // load a valid neighbouring entry and drop it.
                 int bx[G * B], by[G * B], bz[G * B];  // (scalar arrays: promoted to registers after unrolling)
 #pragma unroll
                 for (int jj = 0; jj < G; ++jj) {
                     const int j = g0 + jj;
+                    const int last = pe[j] > 0 ? pe[j] - 1 : 0;
 #pragma unroll
                     for (int u = 0; u < B; ++u) {
-                        bx[jj * B + u] = -1; by[jj * B + u] = -1; bz[jj * B + u] = 0;
-                        if (((need >> j) & 1u) && fl[j] + u < pe[j]) {
-                            const int4 t = cdesc[(size_t)cs[j] + fl[j] + u];
-                            bx[jj * B + u] = t.x; by[jj * B + u] = t.y; bz[jj * B + u] = t.z;
-                        }
+                        const int pos = fl[j] + u < pe[j] ? fl[j] + u : last;
+                        const int4 t = cdesc[(size_t)cs[j] + pos];
+                        bx[jj * B + u] = t.x; by[jj * B + u] = t.y; bz[jj * B + u] = t.z;
                     }
                 }
 #pragma unroll
@@ -746,12 +751,17 @@ k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_star
                 }
             }
         }
+        if (DBG && dbg && ll == 0 && blockIdx.x == 0) { atomicAdd(&dbg[4], (u64)passes); atomicAdd(&dbg[5], (u64)idle_passes); }
         return;
     }
-    // ---- workers
-    int p[MPL], pend[MPL], mine[MPL];
-    int4 d[MPL];
+    // ---- workers: one branch-light trip = every LDS read of the trip issued together (ring poll,
+    // FIFO count, the descriptor FOLLOWING the one held), one wait, then the decision.  A lane that
+    // completes an event takes the next descriptor in the same trip and polls for it in the next.
+    // All addressing is 32-bit (LDS indices; byte offsets against the uniform column base — WIDE
+    // selects 64-bit row offsets for tables beyond 4 GB).
+    int p[MPL], pend[MPL], mine[MPL], ev[MPL], opar[MPL], ridx[MPL];
     bool have[MPL];
+    char* const Lcol = reinterpret_cast<char*>(L + col);
 #pragma unroll
     for (int q = 0; q < MPL; ++q) {
         const int m = tid + q * NT;
@@ -759,7 +769,7 @@ k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_star
         pend[q] = pos1[m];
         mine[q] = -1;
         have[q] = false;
-        d[q] = make_int4(-1, -1, 0, 0);
+        ev[q] = -1; opar[q] = -1; ridx[q] = 0;
         if (p[q] > 0 && p[q] < pend[q]) {  // the member's latest event of an earlier kernel: its row is the self-parent's row
             const int prev = chain_ev[chain_start[m] + p[q] - 1];
             mine[q] = L[(size_t)prev * npad + col];
@@ -767,58 +777,79 @@ k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_star
     }
 #pragma unroll
     for (int q = 0; q < MPL; ++q) asm volatile("" : "+v"(mine[q]));  // the prologue loads are complete before the loop
+    int n_mem = 0, n_done = 0, n_starved = 0, n_iter = 0;
     for (int spins = 0;; ++spins) {
-        bool busy = false, progressed = false;
         if (spins > SPIN_LIMIT) { if ((tid & 63) == 0) atomicExch(err, 1); break; }
+        if (DBG) ++n_iter;
         SW_CBAR();
+        u64 pr[MPL];
+        int fcnt[MPL];
+        int4 nd[MPL];
 #pragma unroll
         for (int q = 0; q < MPL; ++q) {
             const int m = tid + q * NT;
-            if (!have[q] && p[q] < pend[q]) {
-                const int f = filled[m];
-                if (p[q] < f) {
-                    SW_CBAR();
-                    d[q] = fifo[(size_t)(p[q] & fm) * npad + m];
-                    SW_CBAR();
-                    taken[m] = p[q] + 1;  // the slot may be refilled from here on
-                    have[q] = true;
+            pr[q] = ring[ridx[q]];
+            fcnt[q] = filled[m];
+            SW_CBAR();  // the count is read before the entry it publishes (DS operations stay in order)
+            nd[q] = fifo[((p[q] + (have[q] ? 1 : 0)) & fm) * npad + m];
+        }
+        SW_CBAR();
+        bool busy = false;
+#pragma unroll
+        for (int q = 0; q < MPL; ++q) {
+            const int m = tid + q * NT;
+            const int o = opar[q];
+            const int tag = (int)(unsigned)pr[q];
+            const bool hit = tag == o;
+            int other = hit ? (int)(pr[q] >> 32) : -1;
+            bool ready = have[q] && (o < 0 || hit);
+            // rare: the other-parent's row must come from memory (an earlier kernel's event, or a ring
+            // slot that was reused: the row is then >= H store instructions old)
+            const bool from_mem = have[q] && o >= 0 && !hit && (o < first_event || tag > o);
+            if (__ballot(from_mem)) {
+                if (from_mem) {
+                    other = load_sc1_and_wait(WIDE ? &L[(size_t)o * npad + col]
+                                                   : reinterpret_cast<const int*>(Lcol + (unsigned)o * (unsigned)(npad * 4)));
+                    ready = true;
+                    if (DBG) ++n_mem;
                 }
             }
-            if (have[q]) {
-                int other = -1;
-                bool ready = true;
-                const int o = d[q].y;
-                if (o >= 0) {
-                    bool from_mem = o < first_event;
-                    if (!from_mem) {
-                        const int co = d[q].z & 1023, so = (d[q].z >> 10) & hm;
-                        const u64 pr = ring[(size_t)so * npad + co];
-                        const int tag = (int)(unsigned)pr;
-                        if (tag == o) other = (int)(pr >> 32);
-                        else if (tag > o) from_mem = true;   // slot reused: the row is >= H store instructions old
-                        else ready = false;                  // not produced yet
-                    }
-                    if (from_mem) other = load_sc1_and_wait(&L[(size_t)o * npad + col]);
-                }
-                if (ready) {
-                    const int e = d[q].x;
-                    int v = mine[q] > other ? mine[q] : other;  // maxi(): index order == height order on one chain
-                    if (col == m) v = e;                          // own entry (swirld.py:220)
-                    mine[q] = v;
-                    L[(size_t)e * npad + col] = v;
-                    ring[(size_t)(p[q] & hm) * npad + m] = ((u64)(unsigned)v << 32) | (unsigned)e;
-                    SW_CBAR();
-                    ++p[q];
-                    have[q] = false;
-                    progressed = true;
-                }
+            if (ready) {
+                const int e = ev[q];
+                int v = mine[q] > other ? mine[q] : other;  // maxi(): index order == height order on one chain
+                if (col == m) v = e;                          // own entry (swirld.py:220)
+                mine[q] = v;
+                if (WIDE) L[(size_t)e * npad + col] = v;
+                else *reinterpret_cast<int*>(Lcol + (unsigned)e * (unsigned)(npad * 4)) = v;
+                ring[(p[q] & hm) * npad + m] = ((u64)(unsigned)v << 32) | (unsigned)e;
+                ++p[q];
+                have[q] = false;
+                if (DBG) ++n_done;
+            }
+            const bool want = !have[q] && p[q] < pend[q];
+            if (DBG && want && p[q] >= fcnt[q]) ++n_starved;
+            if (want && p[q] < fcnt[q]) {  // nd[q] is the descriptor of position p[q]
+                ev[q] = nd[q].x;
+                opar[q] = nd[q].y;
+                ridx[q] = ((nd[q].z >> 10) & hm) * npad + (nd[q].z & 1023);
+                have[q] = true;
+                taken[m] = p[q] + 1;  // the slot may be refilled from here on
             }
             busy = busy || p[q] < pend[q];
         }
-        // at most 6 store instructions of this wave in flight (see the reuse argument above)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // at most H - 4 store instructions of this wave in flight (see the reuse argument above): every
+        // store instruction, however few lanes it carries, holds a slot of the wave's in-order counter
+        // until L2 acknowledges it
+        if constexpr (H >= 32) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        else if constexpr (H >= 16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if (!__ballot(busy)) break;
-        if (!__ballot(progressed)) __builtin_amdgcn_s_sleep(1);
+    }
+    if (DBG && dbg && blockIdx.x == 0) {  // diagnostics (SW_DEBUG_TIMING): column 0 only
+        atomicAdd(&dbg[0], (u64)n_done);
+        atomicAdd(&dbg[1], (u64)n_mem);
+        atomicAdd(&dbg[2], (u64)n_starved);
+        if ((tid & 63) == 0) { atomicAdd(&dbg[3], (u64)n_iter); atomicAdd(&dbg[6], 1ull); }
     }
 }
 

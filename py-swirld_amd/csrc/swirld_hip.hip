@@ -107,6 +107,7 @@ struct sw_ctx {
     int BATCH = 24;    // loop iterations between host checks
     int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers; k_cansee_flow); 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
+    int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
     int band_blocks = 512; // workgroups of the resolve+band kernel
@@ -136,6 +137,7 @@ struct sw_ctx {
     DBuf<double> d_ts;
     int* d_err = nullptr;
     int* d_flow_err = nullptr;   // set by k_cansee_flow when a polling loop gives up (protocol bug)
+    u64* d_flow_dbg = nullptr;   // SW_DEBUG_TIMING: counters of the dataflow sweep (column 0)
 };
 
 namespace {
@@ -473,30 +475,49 @@ int launch_cansee(sw_ctx* c, int nlev, int pp) {
 }
 
 // dataflow can_see sweep of the sub-batch whose chain positions are bounds rows i and i + 1
-template <int NW, int MPL, int F, int H>
+template <int NW, int MPL, int F, int H, bool WIDE, bool DBG>
 int launch_cansee_flow_t(sw_ctx* c, int i, int64_t first_event) {
     constexpr int npad = 64 * NW;
     const size_t lds = (size_t)npad * ((size_t)F * 16 + (size_t)H * 8 + 8);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_cansee_flow<NW, MPL, F, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_cansee_flow<NW, MPL, F, H, WIDE, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_cansee_flow<NW, MPL, F, H>), dim3(npad), dim3(npad / MPL + 64), lds, c->stream_cs,
+    hipLaunchKernelGGL((k_cansee_flow<NW, MPL, F, H, WIDE, DBG>), dim3(npad), dim3(npad / MPL + 64), lds, c->stream_cs,
                        (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p,
                        (const int*)c->d_bounds.p + (size_t)i * npad, (const int*)c->d_bounds.p + (size_t)(i + 1) * npad,
-                       (const int*)c->d_chain_ev.p, (int)first_event, c->d_L.p, c->d_flow_err);
+                       (const int*)c->d_chain_ev.p, (int)first_event, c->d_L.p, c->d_flow_err, c->d_flow_dbg);
     c->ctr.kernel_launches++;
     HIPCHK(c, hipGetLastError());
     return SW_OK;
 }
 
+template <int NW, int MPL, int F, int H>
+int launch_cansee_flow_g(sw_ctx* c, int i, int64_t first_event) {
+    // 32-bit row offsets while the can_see table stays below 4 GB
+    const bool wide = (size_t)c->cap * (size_t)(64 * NW) * sizeof(int32_t) >= (1ull << 32);
+    if (c->d_flow_dbg) return wide ? launch_cansee_flow_t<NW, MPL, F, H, true, true>(c, i, first_event)
+                                   : launch_cansee_flow_t<NW, MPL, F, H, false, true>(c, i, first_event);
+    return wide ? launch_cansee_flow_t<NW, MPL, F, H, true, false>(c, i, first_event)
+                : launch_cansee_flow_t<NW, MPL, F, H, false, false>(c, i, first_event);
+}
+
 template <int NW>
 int launch_cansee_flow(sw_ctx* c, int i, int64_t first_event) {
-    if constexpr (NW <= 4) return launch_cansee_flow_t<NW, 1, 16, 32>(c, i, first_event);
-    else if constexpr (NW == 8) return launch_cansee_flow_t<8, 2, 8, 16>(c, i, first_event);   // 256 lanes x 2 chains
-    else return launch_cansee_flow_t<16, 4, 4, 8>(c, i, first_event);                          // 256 lanes x 4 chains
+    if constexpr (NW <= 4) {
+        // LDS footprint matters beyond this kernel: the round-loop kernels share the CU with it, and a
+        // 133 KB workgroup leaves room for fewer of their workgroups (SW_FLOW_CFG: FIFO / ring depths)
+        switch (c->flow_cfg) {
+            case 0: return launch_cansee_flow_g<NW, 1, 16, 32>(c, i, first_event);
+            case 2: return launch_cansee_flow_g<NW, 1, 16, 16>(c, i, first_event);
+            case 3: return launch_cansee_flow_g<NW, 1, 8, 32>(c, i, first_event);
+            default: return launch_cansee_flow_g<NW, 1, 8, 16>(c, i, first_event);
+        }
+    }
+    else if constexpr (NW == 8) return launch_cansee_flow_g<8, 2, 8, 16>(c, i, first_event);   // 256 lanes x 2 chains
+    else return launch_cansee_flow_g<16, 4, 4, 8>(c, i, first_event);                          // 256 lanes x 4 chains
 }
 
 LoopBufs loop_bufs(sw_ctx* c) {
@@ -1251,9 +1272,14 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
+    if (const char* s = getenv("SW_FLOW_CFG")) c->flow_cfg = atoi(s);
     if (const char* s = getenv("SW_ELECT_IMPL")) c->elect_impl = atoi(s);
     if (const char* s = getenv("SW_GALLOP")) c->gallop_after = std::max(0, atoi(s));
     c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
+    if (c->debug_timing) {
+        if (hipMalloc(&c->d_flow_dbg, 8 * sizeof(u64)) != hipSuccess) c->d_flow_dbg = nullptr;
+        else (void)hipMemset(c->d_flow_dbg, 0, 8 * sizeof(u64));
+    }
     if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
         if (hipMalloc(&c->d_dbg, (size_t)SW_DBG_MAX_ITERS * 32 * 8) != hipSuccess) c->d_dbg = nullptr;
         else (void)hipMemset(c->d_dbg, 0, (size_t)SW_DBG_MAX_ITERS * 32 * 8);
@@ -1350,6 +1376,13 @@ int sw_destroy(sw_ctx* c) {
     if (!c) return SW_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->debug_timing && c->d_flow_dbg) {
+        u64 d[8] = {0};
+        (void)hipMemcpy(d, c->d_flow_dbg, sizeof d, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[sw] dataflow sweep, column 0: %llu events, %llu rows re-read from memory, %llu starved lane-trips, %llu wave-trips over %llu wave runs "
+                "(%.1f trips per wave run), loader passes %llu (+%llu idle)\n", d[0], d[1], d[2], d[3], d[6], d[6] ? (double)d[3] / (double)d[6] : 0.0, d[4], d[5]);
+        (void)hipFree(c->d_flow_dbg);
+    }
     if (c->debug_timing && c->stage_calls > 0) {
         const double k = 1.0 / (double)c->stage_calls;
         fprintf(stderr, "[sw] sw_divide_rounds host stages, us per call over %lld calls: sweeps enqueued %.1f, loop set-up %.1f, "
