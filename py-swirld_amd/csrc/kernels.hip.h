@@ -974,7 +974,7 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // band event, NW ballots).
 template <int NW>
 __global__ void __launch_bounds__(1024)
-k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARCAP, int MCAP, int Rcap,
+k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
                const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb) {
@@ -986,7 +986,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARC
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.lo_next); pin_arg(B.pos_next);
     pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
-    pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
+    pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
     pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
     const RState* si = B.st + par;
@@ -1040,8 +1040,23 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARC
     // everything before it, a passing slot f > 0 brackets the first passing position in
     // (slot f-1, slot f], which one contiguous window covers.  A strided window falls back to a
     // contiguous one at a far candidate and at the end of the chain.
-    int strd = gsv & 0xff, miss = gsv >> 8;
-    if (iter > 0 && un) {
+    // WINDOW OFFSET (SW_SKIP, tests/model_bulk.py bulk_rounds_v3(skip=...)): the window of a fresh
+    // round starts `skip` positions after the cursor (the first positions after a witness practically
+    // never pass; the first passing position lies 13.8 +- 3.7 after the cursor at 256 members), which
+    // spares most of the rounds that need a second look with K = 28.  A passing or far slot 0 of such
+    // a window only brackets the first passing position in [cursor, cursor + skip]: the member looks
+    // again from the cursor; a failing slot 0 rules out the skipped positions as well.
+    int strd = gsv & 0xff, miss = (gsv >> 8) & 0xff, skp = (gsv >> 16) & 0xff;
+    bool refined = false;
+    if (iter > 0 && un && skp) {
+        if ((fnd == 0 && jf != 0) || jf == 0) {  // look again from the cursor
+            evaluated = jf != SW_INF ? jf : (clen - curc < K ? clen - curc : K);  // (tallies of the offset window)
+            curc -= skp;
+            refined = true;
+        }
+        skp = 0;
+    }
+    if (iter > 0 && un && !refined) {
         // slots offered by the previous launch: positions curc + j * strd < clen, j < K
         const int offered = strd == 1 ? (clen - curc < K ? clen - curc : K)
                                       : ((clen - 1 - curc) / strd + 1 < K ? (clen - 1 - curc) / strd + 1 : K);
@@ -1054,8 +1069,11 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARC
                 my_lo_next = B.cand[((size_t)par * npad + c) * 64 + 1 + fnd];
                 // the next round's window of this member starts here; fetch its last candidate in the
                 // same memory round trip (used for the band range if the round is entered right away)
-                spec_cur = my_pos_next;
-                spec_last = chain_ev[cs + (clen - my_pos_next < K ? clen : my_pos_next + K) - 1];
+                {   // (the window of the next round: offset by `skip` when that leaves a candidate)
+                    const int w0 = my_pos_next + skip < clen ? my_pos_next + skip : my_pos_next;
+                    spec_cur = w0;
+                    spec_last = chain_ev[cs + (clen - w0 < K ? clen : w0 + K) - 1];
+                }
                 un = 0;
             } else {  // bracketed by a strided window: look at (slot fnd-1, slot fnd] next
                 curc += (fnd - 1) * strd + 1;
@@ -1154,10 +1172,13 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARC
             if (r + 1 >= Rcap) { err = 1; done = 1; break; }
             const int act = lr != SW_INF;
             un = 0;
+            skp = 0;
             if (act && nx == SW_INF) {
-                if (evr_now == r && evp_now > start) start = evp_now;
+                bool resumed = false;
+                if (evr_now == r && evp_now > start) { start = evp_now; resumed = true; }
                 curc = start;
                 un = start < clen;
+                if (un && !resumed && skip > 0 && start + skip < clen) { curc = start + skip; skp = skip; }
             }
             // count(act), count(un), min(lr over the active members) with one barrier; the LDS
             // slots alternate between passes of this loop (a wave is at most one barrier ahead)
@@ -1271,7 +1292,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int NEARC
             B.found[out + c] = SW_INF;
             B.farslot[out + c] = SW_INF;
             B.force[out + c] = frc;
-            B.gallop[out + c] = strd | (miss << 8);
+            B.gallop[out + c] = strd | (miss << 8) | (skp << 16);
         }
         if (c == 0) {
             RState t = *si;

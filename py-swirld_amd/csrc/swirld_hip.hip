@@ -98,6 +98,7 @@ struct sw_ctx {
     int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
 
     // tuning
+    int skip = 2;         // SW_SKIP: window offset of a fresh round (0 = off)
     int gallop_after = 0; // strided candidate windows after this many windows without a passing candidate (0 = never)
     int elect_impl = 1; // 1: NW threads per candidate where npad * NW <= 1024 (k_elections_split), 0: one thread per candidate
     int K = 28;        // candidates per member per tally launch: 7 waves per SIMD (the 8th slot is
@@ -547,7 +548,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
     const LoopBufs B = loop_bufs(c);
     Span sr{};
     if (resolve_spans) sr = span_begin(c);
-    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after,
+    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
                        (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW);
@@ -588,7 +589,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     memset(&key, 0, sizeof key);
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
-    key.BATCH = c->band_blocks; key.MCAP = c->MCAP + 7 * c->NEARCAP;
+    key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
         for (int g = 0; g < 3; ++g) {
             if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
@@ -1275,6 +1276,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_FLOW_CFG")) c->flow_cfg = atoi(s);
     if (const char* s = getenv("SW_ELECT_IMPL")) c->elect_impl = atoi(s);
     if (const char* s = getenv("SW_GALLOP")) c->gallop_after = std::max(0, atoi(s));
+    if (const char* s = getenv("SW_SKIP")) c->skip = std::max(0, std::min(32, atoi(s)));
     c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
     if (c->debug_timing) {
         if (hipMalloc(&c->d_flow_dbg, 8 * sizeof(u64)) != hipSuccess) c->d_flow_dbg = nullptr;

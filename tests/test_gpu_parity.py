@@ -248,6 +248,26 @@ def test_election_kernel_variants_agree(pkg, monkeypatch, elect):
         h.close()
 
 
+@pytest.mark.parametrize("skip,gallop,k", [("0", "0", "28"), ("1", "0", "8"), ("2", "2", "4"), ("5", "0", "4"), ("3", "1", "16"),
+                                           ("9", "0", "28"), ("2", "0", "63")])
+def test_window_offset_and_gallop_agree(pkg, monkeypatch, skip, gallop, k):
+    """Window offset of fresh rounds (SW_SKIP) and strided windows (SW_GALLOP) only change which
+    candidates a launch looks at, never the results: slow members, cliques, hot members, tiny
+    hashgraphs (offset larger than a chain), batch and incremental schedules."""
+    monkeypatch.setenv("SW_SKIP", skip)
+    monkeypatch.setenv("SW_GALLOP", gallop)
+    monkeypatch.setenv("SW_TALLY_K", k)
+    for n, N, seed, mode, p0, p1, chunk in [(48, 15000, 95, 2, 0.2, 0.03, None), (16, 6000, 96, 1, 0.01, 0, 700),
+                                            (64, 30000, 97, 2, 0.9, 0.004, None), (130, 14000, 98, 0, 0, 0, 3000),
+                                            (4, 1500, 99, 0, 0, 0, 9), (256, 30000, 100, 0, 0, 0, None)]:
+        stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+        o, ncs_o = oracle_run(n, stream, chunk=chunk)
+        h, ncs_h = hip_run(pkg, n, stream, chunk=chunk)
+        assert ncs_h == ncs_o
+        assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+        h.close()
+
+
 @pytest.mark.parametrize("pipe", ["1", "3", "8"])
 def test_pipelined_subbatches_match_oracle(pkg, monkeypatch, pipe):
     """One big divide_rounds call is internally split into sub-batches whose can_see sweeps

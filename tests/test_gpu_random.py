@@ -23,6 +23,9 @@ def test_random_shapes(pkg, monkeypatch, seed):
         monkeypatch.setenv("SW_BAND_MAX", str(int(rng.choice([64, 1024, 1 << 20]))))
     monkeypatch.setenv("SW_CANSEE_IMPL", str(int(rng.choice([0, 1, 2, 3, 4, 5, 5, 6, 6, 6]))))
     monkeypatch.setenv("SW_TALLY_IMPL", str(int(rng.choice([0, 1, 1]))))
+    monkeypatch.setenv("SW_SKIP", str(int(rng.choice([0, 1, 2, 2, 3, 7]))))
+    if rng.random() < 0.25:
+        monkeypatch.setenv("SW_GALLOP", str(int(rng.choice([1, 2, 3]))))
     cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 9000 + seed, mode, p0, p1)
     t = t + rng.integers(0, 3, N) * 0.5
     stake = None
