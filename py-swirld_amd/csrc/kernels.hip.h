@@ -868,17 +868,38 @@ k_chain_bounds(const int* __restrict__ chain_start, const int* __restrict__ chai
     out[(size_t)i * npad + m] = a;
 }
 
-// pool-indexed chain descriptors for the events [first, first + K): {event, other-parent,
-// creator(op) | (seq(op) & 63) << 10, self-parent}
-__global__ void k_chain_desc(const int* __restrict__ cr, const int* __restrict__ sp, const int* __restrict__ op,
-                             const int* __restrict__ seq, const int* __restrict__ chain_start, int first, int K, int4* cdesc) {
+// Ingest: chain pool entry and pool-indexed chain descriptor {event, other-parent,
+// creator(op) | (seq(op) & 63) << 10, self-parent} of the events [first, first + K).
+__global__ void k_chain_scatter(const int* __restrict__ cr, const int* __restrict__ sp, const int* __restrict__ op,
+                                const int* __restrict__ seq, const int* __restrict__ chain_start, int first, int K,
+                                int* chain_ev, int4* cdesc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     const int e = first + i;
     const int o = op[e];
     int w = 0;
     if (o >= 0) w = cr[o] | ((seq[o] & 63) << 10);
-    cdesc[(size_t)chain_start[cr[e]] + seq[e]] = make_int4(e, o, w, sp[e]);
+    const size_t at = (size_t)chain_start[cr[e]] + seq[e];
+    chain_ev[at] = e;
+    cdesc[at] = make_int4(e, o, w, sp[e]);
+}
+
+// Ingest: the part of is_valid_event's parent check (swirld.py:104-108) that needs a lookup —
+// "the other-parent is by another member" — for a bulk append, on the device; err = smallest
+// offending event index (INT_MAX: none).  (Arity, order and the fork / same-creator test of the
+// self-parent only need per-member tables and run in the host pass.)
+__global__ void k_validate_other_parent(const int* __restrict__ cr, const int* __restrict__ op, int first, int K, int* err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int e = first + i;
+    const int o = op[e];
+    if (o >= 0 && cr[o] == cr[e]) atomicMin(err, e);
+}
+
+// Ingest: coin bit of every event = top bit of the first signature byte (swirld.py:272)
+__global__ void k_coin_bits(const unsigned char* __restrict__ sig, int first, int K, unsigned char* coin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) coin[first + i] = sig[(size_t)(first + i) * 64] >> 7;
 }
 
 // ---------------------------------------------------------------------------------
@@ -2378,11 +2399,6 @@ k_order_sort(const int* __restrict__ acc_ev, const long long* __restrict__ acc_o
         if (i + 1 < cnt && s_ts[i] == s_ts[i + 1] && s_k8[i] == s_k8[i + 1]) tie = 1;
     }
     if (__syncthreads_or(tie) && tid == 0) host_flag[ri] = 1;
-}
-
-__global__ void k_scatter_i32(const int* __restrict__ idx, const int* __restrict__ val, int n, int* dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[idx[i]] = val[i];
 }
 
 __global__ void k_fill_i32(int* p, size_t n, int v) {

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/swirld_hip.h"
@@ -47,9 +48,13 @@ struct sw_ctx {
     std::vector<int32_t> head;      // latest event per member (-1 none)
     std::vector<int32_t> first_ev;  // first event (root) per member (-1 none)
     std::vector<int32_t> nev;       // events per member so far (next chain position)
-    struct AppendRec { int64_t first, K; int hmin, hmax; };
-    std::vector<AppendRec> appends;  // per sw_append_events call: range and height span (ingest-time metadata)
-    bool has_forks = false;
+    bool pool_h_valid = true;       // chain_ev_h mirrors the device pool (bulk appends invalidate it)
+    bool poisoned = false;          // a HIP failure left the context half-updated: every later call fails
+    hipStream_t stream_io = nullptr;  // payload (timestamps, signatures) uploads of bulk appends
+    hipEvent_t ev_payload = nullptr;  // ... and their completion (find_order / coin bits wait for it)
+    bool payload_pending = false;
+    char* h_pin = nullptr;          // pinned staging of bulk appends
+    size_t h_pin_cap = 0;
     int max_height = 0;
     int64_t N = 0, cap = 0, divided = 0;
 
@@ -60,7 +65,6 @@ struct sw_ctx {
     DBuf<u64> d_S;
     DBuf<int32_t> d_chain_start;  // npad: offset of each member's segment in the chain pool
     DBuf<int32_t> d_chain_cnt;    // npad: events per member (segments have slack: geometric growth)
-    DBuf<int32_t> d_scat_idx, d_scat_val;
     DBuf<int4> d_cdesc;           // pool-indexed chain descriptors of the dataflow can_see sweep (same indexing as chain_ev)
     DBuf<int32_t> d_bounds;       // [cuts][npad] chain positions of the sub-batch cuts of the running divide_rounds call
     DBuf<long long> d_cuts;
@@ -98,7 +102,7 @@ struct sw_ctx {
     int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
 
     // tuning
-    int skip = 2;         // SW_SKIP: window offset of a fresh round (0 = off)
+    int skip = 1;         // SW_SKIP: window offset of a fresh round (0 = off); 1 measured best at 256 members (310 vs 326 iterations)
     int gallop_after = 0; // strided candidate windows after this many windows without a passing candidate (0 = never)
     int elect_impl = 1; // 1: NW threads per candidate where npad * NW <= 1024 (k_elections_split), 0: one thread per candidate
     int K = 28;        // candidates per member per tally launch: 7 waves per SIMD (the 8th slot is
@@ -296,94 +300,134 @@ int upload_chain_index(sw_ctx* c) {
     return SW_OK;
 }
 
-// chain descriptors of the events [first, first + K) (needs cr/sp/op/seq/chain_start on the device)
-int build_chain_desc(sw_ctx* c, int64_t first, int64_t K) {
+// Chain pool entries and chain descriptors of the events [first, first + K): one device pass over
+// cr / sp / op / seq with the CURRENT segment offsets (no host loop, no pool upload).
+int scatter_chains(sw_ctx* c, int64_t first, int64_t K) {
     if (K <= 0) return SW_OK;
-    hipLaunchKernelGGL(k_chain_desc, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_cr.p,
+    hipLaunchKernelGGL(k_chain_scatter, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_cr.p,
                        (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
-                       (int)first, (int)K, c->d_cdesc.p);
+                       (int)first, (int)K, c->d_chain_ev.p, c->d_cdesc.p);
     c->ctr.kernel_launches++;
     HIPCHK(c, hipGetLastError());
     return SW_OK;
 }
 
-int rebuild_chains(sw_ctx* c) {
+// Bulk layout: every member gets a fresh segment sized from its event count `cnt` (with slack), and
+// the whole pool is re-scattered on the device.  The host copy of the pool becomes stale.
+int rebuild_chains(sw_ctx* c, const std::vector<int32_t>& cnt, int64_t n_events) {
     const int np = c->npad, n = c->n;
-    std::vector<int32_t> cnt(n, 0);
-    for (int64_t e = 0; e < c->N; ++e) cnt[c->cr[e]]++;
-    c->chain_start_h.assign(np, 0);
-    c->chain_cap.assign(n, 0);
+    std::vector<int32_t> start(np, 0), cap(n, 0);
     int64_t off = 0;
     for (int m = 0; m < n; ++m) {
-        c->chain_start_h[m] = (int32_t)off;
-        c->chain_cap[m] = cnt[m] + cnt[m] / 4 + 16;
-        off += c->chain_cap[m];
+        start[m] = (int32_t)off;
+        cap[m] = cnt[m] + cnt[m] / 4 + 16;
+        off += cap[m];
     }
     if (off > 0x7fffffff) return fail(c, SW_ERANGE, "chain pool exceeds 2^31 entries");
-    c->pool_used = off;
-    c->chain_ev_h.assign((size_t)off, -1);
-    std::vector<int32_t> fillp(n, 0);
-    for (int64_t e = 0; e < c->N; ++e) {
-        const int m = c->cr[e];
-        c->chain_ev_h[(size_t)c->chain_start_h[m] + fillp[m]++] = (int32_t)e;
-    }
     CHK(dgrow(c, c->d_chain_ev, (size_t)off + (size_t)off / 2 + 1024, 0));
-    if (off)
-        HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p, c->chain_ev_h.data(), (size_t)off * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    CHK(upload_chain_index(c));
     CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, 0));
-    return build_chain_desc(c, 0, c->N);
+    c->chain_start_h.swap(start);
+    c->chain_cap.swap(cap);
+    c->pool_used = off;
+    c->pool_h_valid = false;
+    std::vector<int32_t> cntp(np, 0);
+    std::copy(cnt.begin(), cnt.end(), cntp.begin());
+    HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, c->chain_start_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_chain_cnt.p, cntp.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the staging vectors above are locals)
+    return scatter_chains(c, 0, n_events);
 }
 
-// events [N0, N0 + K) were just stored: add them to their members' segments
-int extend_chains(sw_ctx* c, int64_t N0, int64_t K) {
-    std::vector<int32_t> sidx, sval;
-    sidx.reserve(K); sval.reserve(K);
-    std::vector<int32_t> filled(c->n);  // chain length before this append
-    for (int m = 0; m < c->n; ++m) filled[m] = c->nev[m];
-    for (int64_t e = N0; e < N0 + K; ++e) filled[c->cr[e]]--;
-    for (int64_t e = N0; e < N0 + K; ++e) {
-        const int m = c->cr[e];
-        if (filled[m] == c->chain_cap[m]) {  // segment full: move it to the end of the pool, doubled
-            const int32_t ncap = std::max(16, 2 * c->chain_cap[m]);
-            if (c->pool_used + ncap > 0x7fffffff) return fail(c, SW_ERANGE, "chain pool exceeds 2^31 entries");
-            const int64_t noff = c->pool_used;
-            c->chain_ev_h.resize((size_t)(noff + ncap), -1);
-            std::copy(c->chain_ev_h.begin() + c->chain_start_h[m], c->chain_ev_h.begin() + c->chain_start_h[m] + filled[m],
-                      c->chain_ev_h.begin() + noff);
-            CHK(dgrow(c, c->d_chain_ev, (size_t)(noff + ncap) * 2, (size_t)c->pool_used));
-            CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, (size_t)c->pool_used));
-            if (filled[m]) {
-                HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p + noff, c->d_chain_ev.p + c->chain_start_h[m], (size_t)filled[m] * sizeof(int32_t),
-                                         hipMemcpyDeviceToDevice, c->stream));
-                // (the descriptors of events appended earlier in this call are written below, after the move)
-                HIPCHK(c, hipMemcpyAsync(c->d_cdesc.p + noff, c->d_cdesc.p + c->chain_start_h[m], (size_t)filled[m] * sizeof(int4),
-                                         hipMemcpyDeviceToDevice, c->stream));
-            }
-            // entries of this member appended earlier in this call are still pending in the scatter
-            // list: re-target them to the new segment
-            const int32_t old0 = c->chain_start_h[m], old1 = old0 + c->chain_cap[m];
-            for (auto& at : sidx)
-                if (at >= old0 && at < old1) at += (int32_t)(noff - old0);
-            c->chain_start_h[m] = (int32_t)noff;
-            c->chain_cap[m] = ncap;
-            c->pool_used = noff + ncap;
+// Small append: events [N0, N0 + K) with creators cr_new[] join their members' segments in place; a
+// full segment moves to the end of the pool, doubled (device-to-device).  O(K + members).
+int extend_chains(sw_ctx* c, int64_t N0, int64_t K, const int32_t* cr_new, const std::vector<int32_t>& cnt_after) {
+    const int np = c->npad, n = c->n;
+    std::vector<int32_t> before(cnt_after.begin(), cnt_after.begin() + n);
+    for (int64_t i = 0; i < K; ++i) before[cr_new[i]]--;
+    for (int m = 0; m < n; ++m) {
+        if (cnt_after[m] <= c->chain_cap[m]) continue;
+        int32_t ncap = std::max(16, 2 * c->chain_cap[m]);
+        while (ncap < cnt_after[m]) ncap *= 2;
+        if (c->pool_used + ncap > 0x7fffffff) return fail(c, SW_ERANGE, "chain pool exceeds 2^31 entries");
+        const int64_t noff = c->pool_used;
+        CHK(dgrow(c, c->d_chain_ev, (size_t)(noff + ncap) * 2, (size_t)c->pool_used));
+        CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, (size_t)c->pool_used));
+        if (before[m]) {
+            HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p + noff, c->d_chain_ev.p + c->chain_start_h[m], (size_t)before[m] * sizeof(int32_t),
+                                     hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_cdesc.p + noff, c->d_cdesc.p + c->chain_start_h[m], (size_t)before[m] * sizeof(int4),
+                                     hipMemcpyDeviceToDevice, c->stream));
         }
-        const int32_t at = c->chain_start_h[m] + filled[m]++;
-        c->chain_ev_h[at] = (int32_t)e;
-        sidx.push_back(at);
-        sval.push_back((int32_t)e);
+        if (c->pool_h_valid) {
+            c->chain_ev_h.resize((size_t)(noff + ncap), -1);
+            std::copy(c->chain_ev_h.begin() + c->chain_start_h[m], c->chain_ev_h.begin() + c->chain_start_h[m] + before[m],
+                      c->chain_ev_h.begin() + noff);
+        }
+        c->chain_start_h[m] = (int32_t)noff;
+        c->chain_cap[m] = ncap;
+        c->pool_used = noff + ncap;
     }
-    CHK(dgrow(c, c->d_scat_idx, K, 0));
-    CHK(dgrow(c, c->d_scat_val, K, 0));
-    HIPCHK(c, hipMemcpyAsync(c->d_scat_idx.p, sidx.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_scat_val.p, sval.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_scatter_i32, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_scat_idx.p,
-                       (const int*)c->d_scat_val.p, (int)K, c->d_chain_ev.p);
-    c->ctr.kernel_launches++;
-    CHK(upload_chain_index(c));
-    CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, (size_t)c->pool_used));
-    return build_chain_desc(c, N0, K);
+    if (c->pool_h_valid) {
+        if (c->chain_ev_h.size() < (size_t)c->pool_used) c->chain_ev_h.resize((size_t)c->pool_used, -1);
+        std::vector<int32_t> fill(before);
+        for (int64_t i = 0; i < K; ++i) { const int m = cr_new[i]; c->chain_ev_h[(size_t)c->chain_start_h[m] + fill[m]++] = (int32_t)(N0 + i); }
+    }
+    std::vector<int32_t> cntp(np, 0);
+    std::copy(cnt_after.begin(), cnt_after.begin() + n, cntp.begin());
+    HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, c->chain_start_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_chain_cnt.p, cntp.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return scatter_chains(c, N0, K);
+}
+
+// ---- lazily fetched host mirrors: the device arrays are the source of truth -------------------
+// self / other parents and heights (swirld.py:117-120) of all events: needed by sw_get_height and
+// by the level-bucketed can_see kernels only
+int ensure_dag_h(sw_ctx* c) {
+    const int64_t have = (int64_t)c->sp.size();
+    if (have >= c->N) return SW_OK;
+    const int64_t K = c->N - have;
+    c->sp.resize(c->N); c->op.resize(c->N); c->ht.resize(c->N);
+    HIPCHK(c, hipMemcpyAsync(c->sp.data() + have, c->d_sp.p + have, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->op.data() + have, c->d_op.p + have, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->blk_hmin.resize((size_t)((c->N + 4095) >> 12), 0x7fffffff);
+    c->blk_hmax.resize((size_t)((c->N + 4095) >> 12), -1);
+    for (int64_t e = have; e < c->N; ++e) {
+        const int32_t s_ = c->sp[e], o_ = c->op[e];
+        const int32_t h = s_ < 0 ? 0 : std::max(c->ht[s_], c->ht[o_]) + 1;  // swirld.py:117-120
+        c->ht[e] = h;
+        c->max_height = std::max(c->max_height, h);
+        c->blk_hmin[e >> 12] = std::min(c->blk_hmin[e >> 12], h);
+        c->blk_hmax[e >> 12] = std::max(c->blk_hmax[e >> 12], h);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ht.p + have, c->ht.data() + have, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SW_OK;
+}
+
+// host copy of the chain pool (find_order's segment lists)
+int ensure_pool_h(sw_ctx* c) {
+    if (c->pool_h_valid) return SW_OK;
+    c->chain_ev_h.resize((size_t)c->pool_used);
+    if (c->pool_used) {
+        HIPCHK(c, hipMemcpyAsync(c->chain_ev_h.data(), c->d_chain_ev.p, (size_t)c->pool_used * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->pool_h_valid = true;
+    return SW_OK;
+}
+
+// host copy of the signatures (find_order's host-sort fallback, sw_get_vote's coin bits)
+int ensure_sig_h(sw_ctx* c) {
+    const int64_t have = (int64_t)(c->sig_h.size() / 64);
+    if (have >= c->N) return SW_OK;
+    if (c->payload_pending) { HIPCHK(c, hipEventSynchronize(c->ev_payload)); c->payload_pending = false; }
+    c->sig_h.resize((size_t)c->N * 64);
+    HIPCHK(c, hipMemcpyAsync(c->sig_h.data() + (size_t)have * 64, c->d_sig.p + (size_t)have * 64, (size_t)(c->N - have) * 64,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SW_OK;
 }
 
 // geometry of the streaming can_see kernel for this member count
@@ -783,6 +827,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     int max_nlev = 1;
     int64_t max_k = 1;
     if (!flow) {
+        CHK(ensure_dag_h(c));  // the level-bucketed kernels need the heights (swirld.py:117-120)
         for (int i = 0; i < S; ++i) {
             int hmax;
             height_span(c, cut[i], cut[i + 1], &hmins[i], &hmax);
@@ -818,6 +863,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                            (const int*)c->d_chain_ev.p, (const long long*)c->d_cuts.p, np, c->d_bounds.p);
         c->ctr.kernel_launches++;
         HIPCHK(c, hipMemcpyAsync(bounds_h.data(), c->d_bounds.p, bounds_h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipStreamSynchronize(cs));
     }
     if (!flow) HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, cs));
     for (int i = 0; i < S; ++i) {
@@ -852,20 +898,14 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     float tally_ms = 0.f;
     int tally_launches = 0;
     int r_min = 0x7fffffff;
-    std::vector<int32_t> clen_prev(np, 0), clen(np, 0);
-    for (int m = 0; m < n; ++m) {  // members' visible chain lengths before this call
-        const int32_t* ch = c->chain_ev_h.data() + c->chain_start_h[m];
-        const int len = c->nev[m];
-        clen_prev[m] = (int32_t)(std::lower_bound(ch, ch + len, (int32_t)first) - ch);
-    }
+    // members' visible chain lengths before this call and after every sub-batch: rows of the cut table
+    std::vector<int32_t> clen_prev(bounds_h.begin(), bounds_h.begin() + np), clen(np, 0);
     for (int i = 0; i < S; ++i) {
         const int64_t limit = cut[i + 1];
         int r_start = 0x7fffffff;
         bool row0_dirty = false;
+        std::copy(bounds_h.begin() + (size_t)(i + 1) * np, bounds_h.begin() + (size_t)(i + 2) * np, clen.begin());
         for (int m = 0; m < n; ++m) {
-            const int32_t* ch = c->chain_ev_h.data() + c->chain_start_h[m];
-            const int len = c->nev[m];
-            clen[m] = (int32_t)(std::lower_bound(ch, ch + len, (int32_t)limit) - ch);
             if (clen[m] > clen_prev[m]) {  // member touched by this sub-batch
                 if (c->front[m] < 0) {     // its root (swirld.py:195-198): lo[0][m], chain position 0
                     c->lo0_h[m] = c->first_ev[m];
@@ -950,11 +990,6 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     if (first + K == c->N) std::copy(c->head.begin(), c->head.end(), c->divided_head.begin());
     else for (int64_t e = first; e < first + K; ++e) c->divided_head[c->cr[e]] = (int32_t)e;
     c->divided = first + K;
-    {
-        size_t keep = 0;
-        while (keep < c->appends.size() && c->appends[keep].first + c->appends[keep].K <= c->divided) ++keep;
-        c->appends.erase(c->appends.begin(), c->appends.begin() + keep);
-    }
     c->ctr.events_divided += K;
     c->ctr.rounds = R;
     if (c->profiling) {
@@ -980,6 +1015,7 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     Span sp = span_begin(c);
     int max_c = 0;
     while (max_c < R && c->cons_h[max_c]) ++max_c;
+    if (c->payload_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_payload, 0));  // coin bits of a bulk append
     // voter masks: normally already produced by divide_rounds (per sub-batch, overlapped)
     const uint32_t tot2 = 2u * c->tot;
     if (c->sw_dirty_from < R || R > c->Sw_rows) CHK(launch_voter_masks<NW>(c, std::min(c->sw_dirty_from, R), R, c->stream));
@@ -1071,6 +1107,8 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     rounds.erase(std::unique(rounds.begin(), rounds.end()), rounds.end());
     const int nr = (int)rounds.size();
     if (nr == 0) return SW_OK;
+    CHK(ensure_pool_h(c));
+    if (c->payload_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_payload, 0));  // timestamps / signatures of a bulk append
     if (rounds.front() < 0 || rounds.back() >= c->R)
         return fail(c, SW_ERANGE, "find_order: round outside [0, %d) (KeyError in the reference)", c->R);
     const int rmin = rounds.front(), rmax = rounds.back();
@@ -1161,9 +1199,10 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         bool any_flag = false;
         if (getenv("SW_ORDER_HOST")) std::fill(hostflag.begin(), hostflag.end(), 1);  // test hook: host sort
         for (int i = 0; i < nr; ++i) any_flag = any_flag || hostflag[i];
-        if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts
+        if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts and the signatures
             HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_ts.p, n_acc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            CHK(ensure_sig_h(c));
         }
     }
     lap("times+sort");
@@ -1312,12 +1351,15 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
             CHIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
             CHIP(hipStreamCreateWithPriority(&c->stream_cs, hipStreamNonBlocking, least));
             CHIP(hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, least));
+            CHIP(hipStreamCreateWithPriority(&c->stream_io, hipStreamNonBlocking, least));
         } else {
             (void)hipGetLastError();
             CHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             CHIP(hipStreamCreateWithFlags(&c->stream_cs, hipStreamNonBlocking));
             CHIP(hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking));
+            CHIP(hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking));
         }
+        CHIP(hipEventCreateWithFlags(&c->ev_payload, hipEventDisableTiming));
     }
     CHIP(hipMalloc((void**)&c->d_state, 2 * sizeof(RState)));
     CHIP(hipMemset(c->d_state, 0, 2 * sizeof(RState)));
@@ -1393,7 +1435,7 @@ int sw_destroy(sw_ctx* c) {
     }
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
-    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_scat_idx); dfree(c->d_scat_val); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
@@ -1411,6 +1453,9 @@ int sw_destroy(sw_ctx* c) {
     }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->cs_events) (void)hipEventDestroy(e);
+    if (c->stream_io) { (void)hipStreamSynchronize(c->stream_io); (void)hipStreamDestroy(c->stream_io); }
+    if (c->ev_payload) (void)hipEventDestroy(c->ev_payload);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->stream_cs) (void)hipStreamDestroy(c->stream_cs);
     if (c->stream_aux) (void)hipStreamDestroy(c->stream_aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1426,86 +1471,153 @@ int sw_reserve(sw_ctx* c, int64_t n_events) {
 
 int64_t sw_num_events(const sw_ctx* c) { return c ? c->N : 0; }
 
+// Parallel copy of `bytes` bytes (bulk appends stage t / sig in pinned memory so that the upload
+// can run behind the call; one thread cannot saturate the host memory system).
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<size_t>(std::max(1u, std::min(hw / 2, 8u)), bytes / (4u << 20) + 1);
+    if (nt <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nt) + 63) & ~(size_t)63;
+    for (int i = 0; i < nt; ++i) {
+        const size_t a0 = std::min(bytes, per * i), a1 = std::min(bytes, per * (i + 1));
+        if (a1 > a0) th.emplace_back([=] { memcpy((char*)dst + a0, (const char*)src + a0, a1 - a0); });
+    }
+    for (auto& t : th) t.join();
+}
+
 int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t* self_parent,
                      const int32_t* other_parent, const double* t, const uint8_t* sig64) {
     if (!c) return SW_EINVAL;
+    if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
     if (K < 0 || (K > 0 && (!creator || !self_parent || !other_parent))) return fail(c, SW_EINVAL, "NULL event arrays");
     if (K == 0) return SW_OK;
     if (c->N + K > 0x7ffffff0ll) return fail(c, SW_ERANGE, "more than 2^31 events");
-    // structural validation (swirld.py:104-108) before anything is stored.  A fork (an event whose
-    // self-parent is not its creator's latest event, or a second root) is refused HERE, with the
-    // context untouched: the round-synchronous path needs one self-parent chain per member, and a
-    // stored fork would make every later sw_divide_rounds fail (a liveness hole for Node.main).
-    {
-        std::vector<int32_t> head_tmp(c->head);
-        for (int64_t i = 0; i < K; ++i) {
-            const int64_t e = c->N + i;
-            const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
-            if (m < 0 || m >= c->n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
-            if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
-            if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
-            if (s >= 0) {
-                const int32_t cs = s < c->N ? c->cr[s] : creator[s - c->N];
-                const int32_t co = o < c->N ? c->cr[o] : creator[o - c->N];
-                if (cs != m) return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
-                if (co == m) return fail(c, SW_EINVAL, "event %lld: other-parent is by the same member", (long long)e);
-            }
-            if (head_tmp[m] != s)
-                return fail(c, SW_ENOTSUP, "event %lld is a fork (member %d already has %s): forked hashgraphs are outside the "
-                            "supported domain; nothing was stored", (long long)e, m, s < 0 ? "a root" : "a later event on that self-parent");
-            head_tmp[m] = (int32_t)e;
-        }
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure_events(c, c->N + K));
     const int64_t N0 = c->N;
-    c->cr.resize(N0 + K); c->sp.resize(N0 + K); c->op.resize(N0 + K); c->ht.resize(N0 + K);
-    std::vector<unsigned char> coin(K);
-    std::vector<int32_t> seq(K);
+    const int n = c->n;
+    const bool bulk = K >= 8192 || c->chain_cap.empty() || K * 8 >= N0;
+    // ---- 1. host pass: everything of is_valid_event's structural half (swirld.py:104-108) that needs
+    // only per-member tables, on COPIES of them — nothing is stored before the whole batch is accepted.
+    // Arity; topological order; self-parent = the creator's latest event (which makes it an event
+    // of the same creator and refuses forks: the round-synchronous path needs one self-parent chain
+    // per member, and a stored fork would make every later sw_divide_rounds fail); chain positions.
+    std::vector<int32_t> head_t(c->head), nev_t(c->nev), first_t(c->first_ev), seq(K);
     for (int64_t i = 0; i < K; ++i) {
         const int64_t e = N0 + i;
         const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
-        c->cr[e] = m; c->sp[e] = s; c->op[e] = o;
-        c->ht[e] = s < 0 ? 0 : std::max(c->ht[s], c->ht[o]) + 1;  // swirld.py:117-120
-        c->max_height = std::max(c->max_height, c->ht[e]);
-        if (c->head[m] != s) c->has_forks = true;  // second child of s, or a second root
-        if (c->first_ev[m] < 0) c->first_ev[m] = (int32_t)e;
-        c->head[m] = (int32_t)e;
-        seq[i] = c->nev[m]++;  // position on the member's self-parent chain
-        coin[i] = sig64 ? (unsigned char)(sig64[64 * i] >> 7) : 0;  // swirld.py:272
+        if (m < 0 || m >= n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
+        if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
+        if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
+        if (head_t[m] != s) {
+            if (s >= 0 && (s < N0 ? c->cr[s] : creator[s - N0]) != m)
+                return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
+            return fail(c, SW_ENOTSUP, "event %lld is a fork (member %d already has %s): forked hashgraphs are outside the "
+                        "supported domain; nothing was stored", (long long)e, m, s < 0 ? "a root" : "a later event on that self-parent");
+        }
+        head_t[m] = (int32_t)e;
+        if (first_t[m] < 0) first_t[m] = (int32_t)e;
+        seq[i] = nev_t[m]++;
     }
-    c->sig_h.resize((size_t)(N0 + K) * 64);
-    if (sig64) memcpy(c->sig_h.data() + (size_t)N0 * 64, sig64, (size_t)K * 64);
-    else memset(c->sig_h.data() + (size_t)N0 * 64, 0, (size_t)K * 64);
-    {
-        int hmin = 0x7fffffff, hmax = -1;
-        for (int64_t e = N0; e < N0 + K; ++e) { hmin = std::min(hmin, c->ht[e]); hmax = std::max(hmax, c->ht[e]); }
-        c->appends.push_back({N0, K, hmin, hmax});
+    if (!bulk) {  // small append: the other-parent's creator from the host mirror
+        for (int64_t i = 0; i < K; ++i) {
+            const int32_t o = other_parent[i];
+            if (o >= 0 && (o < N0 ? c->cr[o] : creator[o - N0]) == creator[i])
+                return fail(c, SW_EINVAL, "event %lld: other-parent is by the same member", (long long)(N0 + i));
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    // ---- 2. allocations (still nothing committed)
+    CHK(ensure_events(c, N0 + K));
+    const size_t b4 = (size_t)K * sizeof(int32_t);
+    const bool stage = bulk && (t || sig64);
+    if (stage) {
+        const size_t need = (size_t)K * 72;
+        if (c->payload_pending) { HIPCHK(c, hipEventSynchronize(c->ev_payload)); c->payload_pending = false; }
+        if (need > c->h_pin_cap) {
+            if (c->h_pin) (void)hipHostFree(c->h_pin);
+            c->h_pin = nullptr; c->h_pin_cap = 0;
+            if (hipHostMalloc((void**)&c->h_pin, need, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, SW_ENOMEM, "hipHostMalloc(%zu bytes) for the ingest staging buffer failed", need);
+            }
+            c->h_pin_cap = need;
+        }
+    }
+    // ---- 3. parent arrays to the (uncommitted) tail of the device arrays; bulk: device half of the validation
+    HIPCHK(c, hipMemcpyAsync(c->d_cr.p + N0, creator, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_sp.p + N0, self_parent, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_op.p + N0, other_parent, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_seq.p + N0, seq.data(), b4, hipMemcpyHostToDevice, c->stream));
+    if (bulk) {
+        int verdict = 0x7fffffff;
+        HIPCHK(c, hipMemcpyAsync(c->d_err, &verdict, sizeof verdict, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_validate_other_parent, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int*)c->d_cr.p, (const int*)c->d_op.p, (int)N0, (int)K, c->d_err);
+        c->ctr.kernel_launches++;
+        HIPCHK(c, hipMemcpyAsync(&verdict, c->d_err, sizeof verdict, hipMemcpyDeviceToHost, c->stream));
+        // the payload is staged while the device validates
+        if (stage) {
+            if (t) parallel_memcpy(c->h_pin, t, (size_t)K * 8);
+            if (sig64) parallel_memcpy(c->h_pin + (size_t)K * 8, sig64, (size_t)K * 64);
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (verdict != 0x7fffffff)
+            return fail(c, SW_EINVAL, "event %d: other-parent is by the same member", verdict);
+    }
+    // ---- 4. commit.  From here on a device failure leaves the context inconsistent: it is poisoned.
+#define PCHK(expr) do { int rc_ = (expr); if (rc_ != SW_OK) { c->poisoned = true; return rc_; } } while (0)
+#define PHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->poisoned = true; \
+        return fail(c, SW_EIO, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+    c->cr.insert(c->cr.end(), creator, creator + K);
+    // the lazily fetched mirrors stay complete when they were complete (a Node appends a few events per
+    // call); after a bulk append they are refilled from the device on demand
+    if (!bulk && (int64_t)c->sp.size() == N0) {
+        c->sp.insert(c->sp.end(), self_parent, self_parent + K);
+        c->op.insert(c->op.end(), other_parent, other_parent + K);
+        c->ht.resize(N0 + K);
         c->blk_hmin.resize((size_t)((N0 + K + 4095) >> 12), 0x7fffffff);
         c->blk_hmax.resize((size_t)((N0 + K + 4095) >> 12), -1);
         for (int64_t e = N0; e < N0 + K; ++e) {
-            c->blk_hmin[e >> 12] = std::min(c->blk_hmin[e >> 12], c->ht[e]);
-            c->blk_hmax[e >> 12] = std::max(c->blk_hmax[e >> 12], c->ht[e]);
+            const int32_t s_ = c->sp[e], o_ = c->op[e];
+            const int32_t h = s_ < 0 ? 0 : std::max(c->ht[s_], c->ht[o_]) + 1;  // swirld.py:117-120
+            c->ht[e] = h;
+            c->max_height = std::max(c->max_height, h);
+            c->blk_hmin[e >> 12] = std::min(c->blk_hmin[e >> 12], h);
+            c->blk_hmax[e >> 12] = std::max(c->blk_hmax[e >> 12], h);
         }
+        PHIP(hipMemcpyAsync(c->d_ht.p + N0, c->ht.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
     }
+    if (!bulk && (int64_t)(c->sig_h.size() / 64) == N0) {
+        c->sig_h.resize((size_t)(N0 + K) * 64);
+        if (sig64) memcpy(c->sig_h.data() + (size_t)N0 * 64, sig64, (size_t)K * 64);
+        else memset(c->sig_h.data() + (size_t)N0 * 64, 0, (size_t)K * 64);
+    }
+    c->head.swap(head_t);
+    c->first_ev.swap(first_t);
     c->N = N0 + K;
-    const size_t b4 = (size_t)K * sizeof(int32_t);
-    HIPCHK(c, hipMemcpyAsync(c->d_cr.p + N0, c->cr.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_sp.p + N0, c->sp.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_op.p + N0, c->op.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_ht.p + N0, c->ht.data() + N0, b4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_seq.p + N0, seq.data(), b4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_coin.p + N0, coin.data(), K, hipMemcpyHostToDevice, c->stream));
-    if (t) HIPCHK(c, hipMemcpyAsync(c->d_t.p + N0, t, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    else HIPCHK(c, hipMemsetAsync(c->d_t.p + N0, 0, (size_t)K * sizeof(double), c->stream));
-    if (sig64) HIPCHK(c, hipMemcpyAsync(c->d_sig.p + (size_t)N0 * 64, sig64, (size_t)K * 64, hipMemcpyHostToDevice, c->stream));
-    else HIPCHK(c, hipMemsetAsync(c->d_sig.p + (size_t)N0 * 64, 0, (size_t)K * 64, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_round.p + N0, 0xff, b4, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller buffers may be released on return
-    // per-member chain index: part of the ingest-time layout of the hashgraph store.  Bulk appends
-    // rebuild it compactly, small appends extend the members' segments in place.
-    if (K >= 4096 || K * 8 >= c->N || c->chain_cap.empty()) CHK(rebuild_chains(c));
-    else CHK(extend_chains(c, N0, K));
+    // payload: timestamps, signatures, coin bits (swirld.py:272) — needed by decide_fame's coin rounds
+    // and by find_order only, so a bulk append uploads them behind the call on their own stream
+    hipStream_t ps = stage ? c->stream_io : c->stream;
+    if (stage) {
+        if (t) PHIP(hipMemcpyAsync(c->d_t.p + N0, c->h_pin, (size_t)K * 8, hipMemcpyHostToDevice, ps));
+        if (sig64) PHIP(hipMemcpyAsync(c->d_sig.p + (size_t)N0 * 64, c->h_pin + (size_t)K * 8, (size_t)K * 64, hipMemcpyHostToDevice, ps));
+    } else {
+        if (t) PHIP(hipMemcpyAsync(c->d_t.p + N0, t, (size_t)K * 8, hipMemcpyHostToDevice, ps));
+        if (sig64) PHIP(hipMemcpyAsync(c->d_sig.p + (size_t)N0 * 64, sig64, (size_t)K * 64, hipMemcpyHostToDevice, ps));
+    }
+    if (!t) PHIP(hipMemsetAsync(c->d_t.p + N0, 0, (size_t)K * 8, ps));
+    if (!sig64) PHIP(hipMemsetAsync(c->d_sig.p + (size_t)N0 * 64, 0, (size_t)K * 64, ps));
+    hipLaunchKernelGGL(k_coin_bits, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ps, (const unsigned char*)c->d_sig.p, (int)N0, (int)K, c->d_coin.p);
+    c->ctr.kernel_launches++;
+    if (stage) { PHIP(hipEventRecord(c->ev_payload, ps)); c->payload_pending = true; }
+    PHIP(hipMemsetAsync(c->d_round.p + N0, 0xff, b4, c->stream));
+    // per-member chain pool + chain descriptors: part of the ingest-time layout of the hashgraph store
+    if (bulk) PCHK(rebuild_chains(c, nev_t, c->N));
+    else PCHK(extend_chains(c, N0, K, creator, nev_t));
+    c->nev.swap(nev_t);
+    PHIP(hipStreamSynchronize(c->stream));  // caller buffers may be released on return (bulk payload: staged copy)
+#undef PCHK
+#undef PHIP
     return SW_OK;
 }
 
@@ -1514,7 +1626,7 @@ int sw_divide_rounds(sw_ctx* c, int64_t first, int64_t K) {
     if (K < 0 || first < 0 || first + K > c->N) return fail(c, SW_ERANGE, "events [%lld, %lld) outside the stored hashgraph", (long long)first, (long long)(first + K));
     if (first != c->divided) return fail(c, SW_EINVAL, "divide_rounds must continue at event %lld (got %lld): every event is divided once, in order", (long long)c->divided, (long long)first);
     if (K == 0) return SW_OK;
-    if (c->has_forks) return fail(c, SW_ENOTSUP, "the hashgraph contains a fork; the round-synchronous path requires one self-parent chain per member");
+    if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
     HIPCHK(c, hipSetDevice(c->device));
     switch (c->nw) {
         case 1: return do_divide<1>(c, first, K);
@@ -1574,14 +1686,16 @@ int sw_reset(sw_ctx* c) {
     std::fill(c->head.begin(), c->head.end(), -1);
     std::fill(c->first_ev.begin(), c->first_ev.end(), -1);
     std::fill(c->nev.begin(), c->nev.end(), 0);
-    c->appends.clear();
     c->blk_hmin.clear(); c->blk_hmax.clear();
-    c->has_forks = false;
     c->max_height = 0;
     c->N = 0;
     c->sig_h.clear();
     c->chain_cap.clear();
+    c->chain_ev_h.clear();
     c->pool_used = 0;
+    c->pool_h_valid = true;
+    if (c->stream_io) HIPCHK(c, hipStreamSynchronize(c->stream_io));  // a payload upload may still be writing t / sig
+    c->payload_pending = false;
     return SW_OK;
 }
 
@@ -1615,6 +1729,8 @@ static int get_i32(sw_ctx* c, const int32_t* src, int64_t first, int64_t K, int3
 int sw_get_height(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
     if (!c || !out) return SW_EINVAL;
     if (first < 0 || K < 0 || first + K > c->N) return fail(c, SW_ERANGE, "range outside the stored hashgraph");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_dag_h(c));
     std::copy(c->ht.begin() + first, c->ht.begin() + first + K, out);
     return SW_OK;
 }
@@ -1686,6 +1802,7 @@ int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
     if (rv <= rc) return SW_OK;
     if (rv >= c->Sw_rows || c->sw_dirty_from <= rv) return fail(c, SW_EINVAL, "votes are available after decide_fame has seen these rounds");
     HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_sig_h(c));
     const int D = rv - rc;
     std::vector<int32_t> wit((size_t)(D + 1) * np);
     std::vector<u64> Sw((size_t)D * np * nw);
