@@ -94,6 +94,23 @@ int sw_divide_rounds(sw_ctx* ctx, int64_t first, int64_t K);
 int sw_decide_fame(sw_ctx* ctx, int32_t* new_rounds, int cap, int* n_new);
 
 /*
+ * Multi-GPU building block (no reference counterpart: the reference is one thread): the
+ * elections of decide_fame are independent per candidate witness (swirld.py:256-272 given
+ * `witnesses` and the voters' strongly-seen sets), so `nparts` contexts holding the same divided
+ * hashgraph can each run the candidate rounds max_c + part, max_c + part + nparts, ... .
+ * sw_decide_fame_partial writes this part's view — famous[R][n_members] (-1 undecided or not
+ * owned) and decided[R] (1: every witness of the round is decided, swirld.py:274-275) — and commits
+ * nothing.  The element-wise MAX of all parts' tables (one all-reduce; py-swirld_amd/partition.py)
+ * given to sw_commit_fame on every part leaves each context exactly as sw_decide_fame() would:
+ * same famous table, consensus set and new_c.  (Node.votes bookkeeping of rounds decided by
+ * another part has no deciding voter recorded.)
+ */
+int sw_decide_fame_partial(sw_ctx* ctx, int part, int nparts, int8_t* famous, uint8_t* decided,
+                           int r_cap, int* r_out);
+int sw_commit_fame(sw_ctx* ctx, const int8_t* famous, const uint8_t* decided, int R,
+                   int32_t* new_rounds, int cap, int* n_new);
+
+/*
  * Node.find_order(new_c) (swirld.py:280-311) for the given rounds (processed in
  * ascending order like sorted(new_c)).  Appends to the internal `transactions` list
  * and writes the newly ordered event indices, in final order, to out_events.

@@ -44,6 +44,8 @@ SIGNATURES = {
     "sw_num_events": (C.c_int64, [_P]),
     "sw_divide_rounds": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "sw_decide_fame": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "sw_decide_fame_partial": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "sw_commit_fame": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "sw_find_order": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "sw_get_height": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_round": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),

@@ -1959,8 +1959,8 @@ template <int NW, bool UNIT>
 __global__ void __launch_bounds__(1024)
 k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsigned char* __restrict__ coin,
             const uint32_t* __restrict__ stake, uint32_t tot2, int coin_period, int max_c, int R,
-            int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc) {
-    const int r = max_c + blockIdx.x;
+            int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc, int* dec_call, int* dec_by, int call_idx, int part, int nparts) {
+    const int r = max_c + part + nparts * (int)blockIdx.x;  // candidate rounds of this part (1 part: all of them)
     const int cx = threadIdx.x;
     const int x = wit[(size_t)r * npad + cx];
     {   // V of SURVEY.md §8d: the reference re-evaluates every witness of rounds max_c+1..max_r as a
@@ -2044,6 +2044,8 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
         if (active && d >= 2) {
             if (!coin_round && best_idx != SW_INF) {
                 fam[(size_t)r * npad + cx] = (signed char)best_v;  // swirld.py:263
+                dec_call[(size_t)r * npad + cx] = call_idx;        // which decide_fame() call decided x, and which voter
+                dec_by[(size_t)r * npad + cx] = best_idx;
                 active = false;
                 any_decided = 1;
                 int le = 0;  // voters after the first decider never evaluate x
@@ -2090,8 +2092,8 @@ template <int NW, bool UNIT>
 __global__ void __launch_bounds__(1024)
 k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsigned char* __restrict__ coin,
                   const uint32_t* __restrict__ stake, uint32_t tot2, int coin_period, int max_c, int R,
-                  int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc) {
-    const int r = max_c + blockIdx.x;
+                  int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc, int* dec_call, int* dec_by, int call_idx, int part, int nparts) {
+    const int r = max_c + part + nparts * (int)blockIdx.x;  // candidate rounds of this part (1 part: all of them)
     const int tid = threadIdx.x;
     const int j = tid / npad, cx = tid - j * npad;  // npad is a multiple of 64: j is uniform in a wave
     const int x = wit[(size_t)r * npad + cx];
@@ -2189,6 +2191,8 @@ k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const
                 any_decided = 1;
                 if (j == 0) {
                     fam[(size_t)r * npad + cx] = (signed char)best_v;  // swirld.py:263
+                    dec_call[(size_t)r * npad + cx] = call_idx;        // which decide_fame() call decided x, and which voter
+                    dec_by[(size_t)r * npad + cx] = best_idx;
                     int le = 0;  // voters after the first decider never evaluate x
                     for (int c = 0; c < npad; ++c) {
                         const int wv = s_wv[c];

@@ -85,6 +85,10 @@ struct sw_ctx {
     int R = 0;     // max round + 1
     DBuf<int32_t> d_lo, d_lopos, d_wit;
     DBuf<signed char> d_fam;
+    DBuf<int32_t> d_dec_call, d_dec_by;  // per witness slot: the decide_fame() call that decided it and the deciding voter (Node.votes bookkeeping)
+    struct FameCall { int max_c, R; int64_t divided; };
+    std::vector<FameCall> fame_calls;    // one record per decide_fame() call
+    std::vector<int32_t> cons_call;      // per round: the call that added it to `consensus` (-1: not yet)
     DBuf<unsigned char> d_cons, d_newc;
     DBuf<u64> d_Sw;
     int Sw_rows = 0;
@@ -243,15 +247,20 @@ int ensure_rounds(sw_ctx* c, int need) {
     CHK(dgrow(c, c->d_lopos, (size_t)nc * np, keep));
     CHK(dgrow(c, c->d_wit, (size_t)nc * np, keep));
     CHK(dgrow(c, c->d_fam, (size_t)nc * np, keep));
+    CHK(dgrow(c, c->d_dec_call, (size_t)nc * np, keep));
+    CHK(dgrow(c, c->d_dec_by, (size_t)nc * np, keep));
     CHK(dgrow(c, c->d_cons, nc, c->Rcap));
     CHK(dgrow(c, c->d_newc, nc, 0));
     const size_t fresh = (size_t)(nc - c->Rcap) * np;
     CHK(fill_i32(c, c->d_lo.p + keep, fresh, SW_INF));
     CHK(fill_i32(c, c->d_lopos.p + keep, fresh, 0));
     CHK(fill_i32(c, c->d_wit.p + keep, fresh, -1));
+    CHK(fill_i32(c, c->d_dec_call.p + keep, fresh, -1));
+    CHK(fill_i32(c, c->d_dec_by.p + keep, fresh, -1));
     HIPCHK(c, hipMemsetAsync(c->d_fam.p + keep, 0xff, fresh, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cons.p + c->Rcap, 0, nc - c->Rcap, c->stream));
     c->cons_h.resize(nc, 0);
+    c->cons_call.resize(nc, -1);
     c->Rcap = nc;
     return SW_OK;
 }
@@ -1008,67 +1017,107 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     return SW_OK;
 }
 
-template <int NW>
-int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
-    const int np = c->npad, R = c->R;
-    c->ev_used = 0;
-    Span sp = span_begin(c);
+// first round not in `consensus` (swirld.py:226-228)
+int first_undecided_round(const sw_ctx* c) {
     int max_c = 0;
-    while (max_c < R && c->cons_h[max_c]) ++max_c;
+    while (max_c < c->R && c->cons_h[max_c]) ++max_c;
+    return max_c;
+}
+
+// voter masks (if stale) + the elections of the candidate rounds max_c + part, max_c + part + nparts, ...
+template <int NW>
+int fame_launch(sw_ctx* c, int max_c, int part, int nparts, Span* sp_el) {
+    const int np = c->npad, R = c->R;
     if (c->payload_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_payload, 0));  // coin bits of a bulk append
     // voter masks: normally already produced by divide_rounds (per sub-batch, overlapped)
     const uint32_t tot2 = 2u * c->tot;
     if (c->sw_dirty_from < R || R > c->Sw_rows) CHK(launch_voter_masks<NW>(c, std::min(c->sw_dirty_from, R), R, c->stream));
     c->sw_dirty_from = std::max(R, 1);
     HIPCHK(c, hipMemsetAsync(c->d_newc.p, 0, R, c->stream));
-    bool split_done = false;
-    Span sp_el = span_begin(c);
-    if constexpr (NW >= 2 && NW <= 4) {  // NW threads per candidate (see k_elections_split): npad * NW <= 1024
-        if (R > max_c && c->elect_impl == 1) {
-            if (c->unit_stake)
-                hipLaunchKernelGGL((k_elections_split<NW, true>), dim3(R - max_c), dim3(np * NW), 0, c->stream, (const int*)c->d_wit.p,
-                                   (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
-                                   tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
-            else
-                hipLaunchKernelGGL((k_elections_split<NW, false>), dim3(R - max_c), dim3(np * NW), 0, c->stream, (const int*)c->d_wit.p,
-                                   (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
-                                   tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
-            c->ctr.kernel_launches++;
-            split_done = true;
+    const int nblk = R - max_c - part > 0 ? (R - max_c - part + nparts - 1) / nparts : 0;
+    const int call_idx = (int)c->fame_calls.size();
+    if (sp_el) *sp_el = span_begin(c);
+    if (nblk > 0) {
+        bool split_done = false;
+#define SW_ELECT_ARGS (const int*)c->d_wit.p, (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p, \
+                      tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc, c->d_dec_call.p, c->d_dec_by.p, call_idx, part, nparts
+        if constexpr (NW >= 2 && NW <= 4) {  // NW threads per candidate (see k_elections_split): npad * NW <= 1024
+            if (c->elect_impl == 1) {
+                if (c->unit_stake) hipLaunchKernelGGL((k_elections_split<NW, true>), dim3(nblk), dim3(np * NW), 0, c->stream, SW_ELECT_ARGS);
+                else hipLaunchKernelGGL((k_elections_split<NW, false>), dim3(nblk), dim3(np * NW), 0, c->stream, SW_ELECT_ARGS);
+                split_done = true;
+            }
         }
-    }
-    if (!split_done && R > max_c) {
-        if (c->unit_stake)
-            hipLaunchKernelGGL((k_elections<NW, true>), dim3(R - max_c), dim3(np), 0, c->stream, (const int*)c->d_wit.p,
-                               (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
-                               tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
-        else
-            hipLaunchKernelGGL((k_elections<NW, false>), dim3(R - max_c), dim3(np), 0, c->stream, (const int*)c->d_wit.p,
-                               (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p,
-                               tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc);
+        if (!split_done) {
+            if (c->unit_stake) hipLaunchKernelGGL((k_elections<NW, true>), dim3(nblk), dim3(np), 0, c->stream, SW_ELECT_ARGS);
+            else hipLaunchKernelGGL((k_elections<NW, false>), dim3(nblk), dim3(np), 0, c->stream, SW_ELECT_ARGS);
+        }
+#undef SW_ELECT_ARGS
         c->ctr.kernel_launches++;
     }
-    span_end(c, sp_el);
+    if (sp_el) span_end(c, *sp_el);
     HIPCHK(c, hipGetLastError());
+    return SW_OK;
+}
+
+void fame_counters(sw_ctx* c, const FameCounters& fc) {
+    c->ctr.voter_evals += (int64_t)(fc.voter_evals - c->fc_seen.voter_evals);
+    c->ctr.majority_evals += (int64_t)(fc.majority_evals - c->fc_seen.majority_evals);
+    c->fc_seen = fc;
+}
+
+template <int NW>
+int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
+    const int R = c->R;
+    c->ev_used = 0;
+    Span sp = span_begin(c), sp_el{};
+    const int max_c = first_undecided_round(c);
+    CHK(fame_launch<NW>(c, max_c, 0, 1, &sp_el));
     std::vector<unsigned char> newc(R);
     FameCounters fc{};
     HIPCHK(c, hipMemcpyAsync(newc.data(), c->d_newc.p, R, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&fc, c->d_fc, sizeof fc, hipMemcpyDeviceToHost, c->stream));
     span_end(c, sp);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int call_idx = (int)c->fame_calls.size();
+    c->fame_calls.push_back({max_c, R, c->divided});
     int cnt = 0;
     for (int r = 0; r < R; ++r)
         if (newc[r]) {
             c->cons_h[r] = 1;
+            c->cons_call[r] = call_idx;
             if (cnt < cap && new_rounds) new_rounds[cnt] = r;
             ++cnt;
         }
     if (n_new) *n_new = cnt;
-    c->ctr.voter_evals += (int64_t)(fc.voter_evals - c->fc_seen.voter_evals);
-    c->ctr.majority_evals += (int64_t)(fc.majority_evals - c->fc_seen.majority_evals);
-    c->fc_seen = fc;
+    fame_counters(c, fc);
     if (c->profiling) { c->tm.fame_ms = span_ms(sp); c->tm.elections_ms = span_ms(sp_el); }
     if (cnt > cap) return fail(c, SW_ERANGE, "new_rounds capacity %d < %d", cap, cnt);
+    return SW_OK;
+}
+
+// Candidate-partitioned decide_fame (multi-GPU row (e)): this part's share of the elections; the
+// context's own tables receive this part's decisions only, nothing enters `consensus` yet.
+template <int NW>
+int do_fame_partial(sw_ctx* c, int part, int nparts, int8_t* famous, uint8_t* decided) {
+    const int np = c->npad, n = c->n, R = c->R;
+    const int max_c = first_undecided_round(c);
+    CHK(fame_launch<NW>(c, max_c, part, nparts, nullptr));
+    std::vector<unsigned char> newc(R);
+    std::vector<signed char> fam((size_t)R * np);
+    FameCounters fc{};
+    HIPCHK(c, hipMemcpyAsync(newc.data(), c->d_newc.p, R, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fam.data(), c->d_fam.p, fam.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&fc, c->d_fc, sizeof fc, hipMemcpyDeviceToHost, c->stream));
+    // the kernel marks the rounds it completed in the device-side consensus flags; they become
+    // official in sw_commit_fame, for every part alike
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < R; ++r) {
+        decided[r] = newc[r];
+        const bool mine = r >= max_c && (r - max_c) % nparts == part;
+        for (int m = 0; m < n; ++m) famous[(size_t)r * n + m] = (r < max_c || mine) ? fam[(size_t)r * np + m] : (signed char)-1;
+    }
+    fame_counters(c, fc);
     return SW_OK;
 }
 
@@ -1437,7 +1486,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
     dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
-    dfree(c->d_fam); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
+    dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
     dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_Mb);
@@ -1653,6 +1702,57 @@ int sw_decide_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     return fail(c, SW_EINVAL, "unsupported member count");
 }
 
+int sw_decide_fame_partial(sw_ctx* c, int part, int nparts, int8_t* famous, uint8_t* decided, int r_cap, int* r_out) {
+    if (!c || !famous || !decided) return SW_EINVAL;
+    if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
+    if (nparts < 1 || part < 0 || part >= nparts) return fail(c, SW_EINVAL, "part %d of %d", part, nparts);
+    if (c->R <= 0) return fail(c, SW_EINVAL, "decide_fame before any witness exists (max() of an empty dict in the reference, swirld.py:225)");
+    if (r_out) *r_out = c->R;
+    if (r_cap < c->R) return fail(c, SW_ERANGE, "famous / decided hold %d rounds, %d needed", r_cap, c->R);
+    HIPCHK(c, hipSetDevice(c->device));
+    switch (c->nw) {
+        case 1: return do_fame_partial<1>(c, part, nparts, famous, decided);
+        case 2: return do_fame_partial<2>(c, part, nparts, famous, decided);
+        case 4: return do_fame_partial<4>(c, part, nparts, famous, decided);
+        case 8: return do_fame_partial<8>(c, part, nparts, famous, decided);
+        case 16: return do_fame_partial<16>(c, part, nparts, famous, decided);
+    }
+    return fail(c, SW_EINVAL, "unsupported member count");
+}
+
+int sw_commit_fame(sw_ctx* c, const int8_t* famous, const uint8_t* decided, int R, int32_t* new_rounds, int cap, int* n_new) {
+    if (!c || !famous || !decided) return SW_EINVAL;
+    if (n_new) *n_new = 0;
+    if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
+    if (R != c->R) return fail(c, SW_EINVAL, "merged table has %d rounds, the context %d", R, c->R);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int np = c->npad, n = c->n;
+    const int max_c = first_undecided_round(c);
+    std::vector<signed char> fam((size_t)(R - max_c) * np, (signed char)-1);
+    std::vector<unsigned char> cons(R - max_c, 0);
+    const int call_idx = (int)c->fame_calls.size();
+    c->fame_calls.push_back({max_c, R, c->divided});
+    int cnt = 0;
+    for (int r = max_c; r < R; ++r) {
+        for (int m = 0; m < n; ++m) fam[(size_t)(r - max_c) * np + m] = famous[(size_t)r * n + m];
+        if (decided[r]) {
+            c->cons_h[r] = 1;
+            c->cons_call[r] = call_idx;
+            if (cnt < cap && new_rounds) new_rounds[cnt] = r;
+            ++cnt;
+        }
+        cons[r - max_c] = c->cons_h[r];
+    }
+    if (R > max_c) {
+        HIPCHK(c, hipMemcpyAsync(c->d_fam.p + (size_t)max_c * np, fam.data(), fam.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_cons.p + max_c, cons.data(), cons.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (n_new) *n_new = cnt;
+    if (cnt > cap) return fail(c, SW_ERANGE, "new_rounds capacity %d < %d", cap, cnt);
+    return SW_OK;
+}
+
 int sw_rewind(sw_ctx* c) {
     if (!c) return SW_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1660,6 +1760,10 @@ int sw_rewind(sw_ctx* c) {
     CHK(fill_i32(c, c->d_lo.p, rows, SW_INF));
     CHK(fill_i32(c, c->d_lopos.p, rows, 0));
     CHK(fill_i32(c, c->d_wit.p, rows, -1));
+    CHK(fill_i32(c, c->d_dec_call.p, rows, -1));
+    CHK(fill_i32(c, c->d_dec_by.p, rows, -1));
+    c->fame_calls.clear();
+    std::fill(c->cons_call.begin(), c->cons_call.end(), -1);
     HIPCHK(c, hipMemsetAsync(c->d_fam.p, 0xff, rows, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cons.p, 0, c->Rcap, c->stream));
     CHK(fill_i32(c, c->d_evalround.p, 2 * c->npad, -1));
@@ -1791,9 +1895,20 @@ int sw_get_sees_mask(sw_ctx* c, int64_t first, int64_t K, uint64_t* out) {
     return SW_OK;
 }
 
-// Node.votes[voter][candidate] (swirld.py:60-61, 256-272), recomputed on the host from the
-// voter masks: the election of one candidate replayed up to the voter's round.  Batch semantics:
-// an entry exists for every voter that evaluated the candidate before it was decided.
+// Node.votes[voter][candidate] (swirld.py:60-61, 256-272).  The elections keep votes as per-round
+// member bitmasks, so an entry is recomputed on demand — with the reference's FULL semantics, call
+// schedule included:
+//  * the VALUE of votes[y][x] is a function of the hashgraph alone (y's strongly-seen set, the
+//    votes of those witnesses, y's coin bit): the election of x is replayed level by level up to
+//    y's round, every witness voting;
+//  * whether the ENTRY exists depends on the decide_fame() calls (Appendix A Q8/Q9): y recorded a
+//    vote on x iff in some call both were registered witnesses, y was a voter (round(y) > max_c of
+//    that call), round(x) was not yet in `consensus`, and x was still undecided when y's turn came
+//    — i.e. the call precedes the one that decided x, or is that call and y comes before the
+//    deciding voter in voter order (rounds ascending, registration order inside a round); the
+//    deciding voter itself stores nothing.  Per call the context keeps (max_c, rounds, events
+//    divided), per round the call that put it into `consensus`, per witness the call and the voter
+//    that decided it (written by the election kernels).
 int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
     if (!c || !out) return SW_EINVAL;
     *out = -1;
@@ -1806,22 +1921,40 @@ int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
     const int D = rv - rc;
     std::vector<int32_t> wit((size_t)(D + 1) * np);
     std::vector<u64> Sw((size_t)D * np * nw);
+    int32_t dec[2] = {-1, -1};
     HIPCHK(c, hipMemcpyAsync(wit.data(), c->d_wit.p + (size_t)rc * np, wit.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(Sw.data(), c->d_Sw.p + (size_t)(rc + 1) * np * nw, Sw.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&dec[0], c->d_dec_call.p + (size_t)rc * np + mc, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&dec[1], c->d_dec_by.p + (size_t)rc * np + mc, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (wit[mc] < 0 || wit[(size_t)D * np + mv] < 0) return SW_OK;  // not witnesses: no entry
+    const int32_t x = wit[mc], y = wit[(size_t)D * np + mv];
+    if (x < 0 || y < 0) return SW_OK;  // not witnesses: no entry
+    // ---- does the entry exist?  calls c0 .. c1 in which y evaluated x
+    const int ncalls = (int)c->fame_calls.size();
+    const int64_t born = (int64_t)std::max(x, y) + 1;  // both are divided (hence registered) once `divided` >= born
+    int c0 = 0;
+    while (c0 < ncalls && c->fame_calls[c0].divided < born) ++c0;
+    int c1 = ncalls - 1;
+    while (c1 >= c0 && c->fame_calls[c1].max_c + 1 > rv) --c1;          // y must be a voter: round(y) >= max_c + 1
+    if (c->cons_call[rc] >= 0) c1 = std::min(c1, c->cons_call[rc]);     // rounds in `consensus` are skipped (swirld.py:233)
+    if (dec[0] >= 0) {
+        int32_t rz = -1;
+        HIPCHK(c, hipMemcpy(&rz, c->d_round.p + dec[1], sizeof rz, hipMemcpyDeviceToHost));
+        const bool before_decider = y != dec[1] && (rv < rz || (rv == rz && y < dec[1]));
+        c1 = std::min(c1, before_decider ? dec[0] : dec[0] - 1);
+    }
+    if (c1 < c0) return SW_OK;
+    // ---- its value: the election of x replayed up to y's level
     std::vector<char> V(n, 0), Vn(n, 0);
     auto sw_bit = [&](int d, int voter, int member) {  // d = 1..D
         return (int)((Sw[((size_t)(d - 1) * np + voter) * nw + (member >> 6)] >> (member & 63)) & 1ull);
     };
-    for (int v = 0; v < n; ++v) V[v] = wit[(size_t)1 * np + v] >= 0 ? (char)sw_bit(1, v, mc) : 0;
+    for (int v = 0; v < n; ++v) V[v] = wit[(size_t)1 * np + v] >= 0 ? (char)sw_bit(1, v, mc) : 0;  // x in s (swirld.py:258)
     if (D == 1) { *out = V[mv]; return SW_OK; }
     const uint64_t tot2 = 2ull * c->tot;
     for (int d = 2; d <= D; ++d) {
         const int32_t* wrow = wit.data() + (size_t)d * np;
         const bool coin_round = (d % c->coin_period) == 0;
-        int first = -1, first_v = 0;
-        std::vector<char> smv(n, 0);
         for (int v = 0; v < n; ++v) {
             Vn[v] = 0;
             if (wrow[v] < 0) continue;
@@ -1829,17 +1962,10 @@ int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
             for (int m = 0; m < n; ++m)
                 if (sw_bit(d, v, m)) { all += c->stake_h[m]; if (V[m]) yes += c->stake_h[m]; }
             const uint64_t no = all - yes;
-            const int vote = !(no > yes);
-            const uint64_t t = vote ? yes : no;
-            smv[v] = 3 * t > tot2;
+            const int vote = !(no > yes);            // majority(): tie -> True (swirld.py:24-27)
+            const uint64_t tt = vote ? yes : no;
             Vn[v] = (char)vote;
-            if (coin_round) { if (!smv[v]) Vn[v] = (char)(c->sig_h[(size_t)wrow[v] * 64] >> 7); }
-            else if (smv[v] && (first < 0 || wrow[v] < wrow[first])) { first = v; first_v = vote; }
-        }
-        (void)first_v;
-        if (!coin_round && first >= 0) {  // decided in this round by `first`: later voters never vote
-            if (d == D && wrow[mv] < wrow[first]) *out = Vn[mv];
-            return SW_OK;
+            if (coin_round && !(3 * tt > tot2)) Vn[v] = (char)(c->sig_h[(size_t)wrow[v] * 64] >> 7);  // swirld.py:272
         }
         if (d == D) { *out = Vn[mv]; return SW_OK; }
         V.swap(Vn);

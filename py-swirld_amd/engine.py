@@ -71,6 +71,27 @@ class Hashgraph:
         self._chk(self._L.sw_decide_fame(self._h, _p(out), int(out.shape[0]), C.byref(n_new)))
         return out[: n_new.value].copy()
 
+    def decide_fame_partial(self, part, nparts):
+        """This part's share of the elections (candidate rounds max_c + part, + nparts, ...):
+        (famous[R][n] int8 with -1 = undecided or not owned, decided[R] uint8); nothing committed."""
+        R = self.max_round + 1
+        fam = np.empty((max(R, 1), self.n), np.int8)
+        dec = np.empty(max(R, 1), np.uint8)
+        r_out = C.c_int()
+        self._chk(self._L.sw_decide_fame_partial(self._h, int(part), int(nparts), _p(fam), _p(dec), R, C.byref(r_out)))
+        return fam[:R], dec[:R]
+
+    def commit_fame(self, famous, decided):
+        """Commit the element-wise MAX of all parts' tables: the context is then exactly as after
+        decide_fame(); returns new_c."""
+        fam = np.ascontiguousarray(famous, np.int8)
+        dec = np.ascontiguousarray(decided, np.uint8)
+        R = dec.shape[0]
+        out = np.empty(max(R, 1), np.int32)
+        n_new = C.c_int()
+        self._chk(self._L.sw_commit_fame(self._h, _p(fam), _p(dec), R, _p(out), int(out.shape[0]), C.byref(n_new)))
+        return out[: n_new.value].copy()
+
     def find_order(self, rounds):
         rounds = np.ascontiguousarray(sorted(int(r) for r in rounds), np.int32)
         cap = self.num_events

@@ -140,6 +140,8 @@ class _VoterVotes(Mapping):
     def _slot(self, h):
         nd = self._n
         e = nd._index[h]
+        if e >= nd._divided:  # known event, not yet through divide_rounds: no round, hence no votes
+            raise KeyError(h)
         return int(nd._rounds()[e]), nd._mindex[nd.hg[h].c]
 
     def __getitem__(self, x):
@@ -169,8 +171,9 @@ class _VoterVotes(Mapping):
 class _VotesView(Mapping):
     """Node.votes: {voter witness -> {candidate witness -> bool}} (swirld.py:60-61).  The GPU
     elections keep votes as per-round member bitmasks; entries are recomputed on demand
-    (sw_get_vote) with the semantics of one batch decide_fame() call: a voter has an entry for
-    every candidate it evaluated before that candidate was decided."""
+    (sw_get_vote) with the reference's full semantics, the decide_fame() call schedule included: a
+    voter has an entry for every candidate it evaluated, in whichever call, before that candidate
+    was decided (Appendix A Q8/Q9)."""
 
     def __init__(self, node):
         self._n = node

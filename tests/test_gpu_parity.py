@@ -80,6 +80,42 @@ def test_votes_match_reference(pkg, name):
     h.close()
 
 
+@pytest.mark.parametrize("name", ["n4_s5_chunk1", "n4_s6_chunk7", "n7_s2_chunk13", "n16_s4_chunk50", "n16_s4_chunk250",
+                                  "n64_s2_slow_chunk1000", "n4_mainloop_node0"])
+def test_votes_match_reference_incremental_schedules(pkg, name):
+    """Node.votes after INCREMENTAL call schedules: the reference's dict also holds the entries of
+    voters that evaluated a candidate in an earlier decide_fame() call, before a later-arriving
+    voter decided it (Appendix A Q8/Q9).  Every entry of the reference and the absence of every
+    other (voter, candidate) pair — exhaustively where the table is small."""
+    g = load_golden(name)
+    assert len(g["batches"]) > 1
+    h = pkg.Hashgraph(g["n"], g["stake"])
+    run_schedule(h, g)
+    rnd, cr, wit = g["round"], g["creator"], g["witnesses"]
+    have = {(int(y), int(x)): int(v) for y, x, v in g["votes"]}
+    assert len(have) == len(g["votes"])
+    R, n = wit.shape
+    slots = [(r, m) for r in range(R) for m in range(n) if wit[r, m] >= 0]
+    pairs = [(sy, sx) for sy in slots for sx in slots if sx[0] < sy[0]]
+    if len(pairs) > 30000:
+        rng = np.random.default_rng(1)
+        keep = {(int(rnd[y]), int(cr[y]), int(rnd[x]), int(cr[x])) for y, x in have}
+        pick = rng.choice(len(pairs), 12000, replace=False)
+        sample = [pairs[i] for i in pick] + [((a, b), (c_, d)) for a, b, c_, d in list(keep)[:12000]]
+    else:
+        sample = pairs
+    n_entries = 0
+    for (rv, mv), (rc, mc) in sample:
+        y, x = int(wit[rv, mv]), int(wit[rc, mc])
+        exp = have.get((y, x), -1)
+        got = h.vote(rv, mv, rc, mc)
+        assert got == exp, "votes[%d][%d]: got %d, reference %d" % (y, x, got, exp)
+        n_entries += exp >= 0
+    if len(pairs) <= 30000:
+        assert n_entries == len(have), "every entry of the reference is a (witness, earlier witness) pair"
+    h.close()
+
+
 def test_fork_is_refused(pkg):
     g = load_golden("n8_s11_forks")
     h = pkg.Hashgraph(g["n"])
