@@ -179,7 +179,7 @@ def main():
         return d
 
     npad = ((n + 63) // 64) * 64
-    cs_impl = int(os.environ.get("SW_CANSEE_IMPL", "6"))
+    cs_impl = int(os.environ.get("SW_CANSEE_IMPL", "6" if npad <= 256 else "3"))
     cs_name = "k_cansee_flow" if cs_impl >= 6 else ("k_cansee_member1b" if npad <= 256 else "k_cansee_stream")
     kernels = [
         fam(cs_name, tm["cansee_launches"], tm["cansee_kernel_ms"], 12 * n * (N - n), "hbm",
@@ -206,7 +206,7 @@ def main():
         "path_note": "whole-pass algorithmic bytes (SURVEY.md §8d) / ms_per_step: the path is bound by its dependency "
                      "chains (DAG levels, rounds), not by bandwidth",
         "counters": {k: cd[k] for k in ("levels", "round_iterations", "tally_evals", "band_events", "voter_evals",
-                                        "majority_evals", "far_hops")},
+                                        "majority_evals", "coin_votes", "coin_flips", "far_hops")},
         "phase_ms": {k: round(v, 3) for k, v in (("can_see_stream_span", tm["can_see_ms"]), ("round_loop_span", tm["rounds_ms"]),
                                                  ("aux_finalize_voter_span", tm["finalize_ms"]), ("fame", tm["fame_ms"]))},
         "phase_note": "profiled pass = plain launches with event pairs (slower than the graph-replayed timed steps); "
@@ -247,6 +247,8 @@ def main():
                        "parallelism": "replicas x%d (no data-path collective; strong-scaling target of north_star unmet)" % world,
                        "rounds": c1["rounds"], "ingest_s_untimed": round(ingest_s, 3),
                        "new_c_last_step": int(len(new_c)),
+                       "coin_round_votes": cd["coin_votes"], "coin_round_votes_from_signature_bit": cd["coin_flips"],
+                       "generator": {"mode": args.mode, "p0": args.p0, "p1": args.p1},
                        "find_order_ms_untimed": round(find_order_ms, 2), "events_ordered": int(len(ordered))},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

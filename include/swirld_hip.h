@@ -154,6 +154,8 @@ typedef struct sw_counters {
     int64_t kernel_launches;
     int64_t far_hops;            /* hop masks rebuilt from rows because the hop lay outside the band */
     int64_t band_events;         /* band events whose threshold mask was built by the round loop      */
+    int64_t coin_votes;          /* votes cast in coin rounds, d % C == 0 (swirld.py:267-272)          */
+    int64_t coin_flips;          /* ... of which taken from the voter's signature bit (swirld.py:272)  */
 } sw_counters;
 int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 

@@ -197,7 +197,8 @@ class Oracle:
         return int(lib().or_votes_digest(self._h))
 
     def counters(self):
-        out = np.zeros(4, np.int64)
+        out = np.zeros(8, np.int64)
         lib().or_get_counters(self._h, _p(out))
         return {"voter_evals": int(out[0]), "majority_evals": int(out[1]),
-                "tally_inner": int(out[2]), "rounds": int(out[3])}
+                "tally_inner": int(out[2]), "rounds": int(out[3]),
+                "coin_votes": int(out[4]), "coin_flips": int(out[5]), "max_vote_distance": int(out[6])}

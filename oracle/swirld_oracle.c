@@ -59,6 +59,8 @@ typedef struct or_ctx {
     int64_t n_tx;
     /* counters */
     int64_t voter_evals, majority_evals, tally_inner;
+    int64_t coin_votes, coin_flips;  /* votes cast in coin rounds (swirld.py:267-272), of which by the signature bit (:272) */
+    int max_dist;                    /* largest voter-candidate round distance evaluated */
 } or_ctx;
 
 static int grow_rounds(or_ctx* o, int need) {
@@ -336,9 +338,11 @@ int or_decide_fame(or_ctx* o, int32_t* new_rounds, int cap, int* n_new) {
                             if (sm) { o->famous[x] = (int8_t)v; done[r] = 1; }
                             else rc = votes_put(o, y, x, v);
                         } else { /* :267-272 */
+                            o->coin_votes++;
                             if (sm) rc = votes_put(o, y, x, v);
-                            else rc = votes_put(o, y, x, o->sig[64 * (size_t)y] / 128);
+                            else { o->coin_flips++; rc = votes_put(o, y, x, o->sig[64 * (size_t)y] / 128); }
                         }
+                        if (d > o->max_dist) o->max_dist = d;
                     }
                 }
             }
@@ -510,6 +514,7 @@ uint64_t or_votes_digest(const or_ctx* o) {
         if (o->votes[i].key) acc += vhash(o->votes[i].key * 2 + (uint64_t)o->votes[i].val);
     return acc;
 }
-void or_get_counters(const or_ctx* o, int64_t* out4) {
-    out4[0] = o->voter_evals; out4[1] = o->majority_evals; out4[2] = o->tally_inner; out4[3] = o->R;
+void or_get_counters(const or_ctx* o, int64_t* out8) {
+    out8[0] = o->voter_evals; out8[1] = o->majority_evals; out8[2] = o->tally_inner; out8[3] = o->R;
+    out8[4] = o->coin_votes; out8[5] = o->coin_flips; out8[6] = o->max_dist; out8[7] = 0;
 }

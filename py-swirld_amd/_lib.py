@@ -22,7 +22,7 @@ class SwirldHipError(RuntimeError):
 class Counters(C.Structure):
     _fields_ = [(k, C.c_int64) for k in (
         "events_divided", "rounds", "tally_evals", "round_iterations", "voter_evals",
-        "majority_evals", "levels", "kernel_launches", "far_hops", "band_events")]
+        "majority_evals", "levels", "kernel_launches", "far_hops", "band_events", "coin_votes", "coin_flips")]
 
 
 class Timings(C.Structure):

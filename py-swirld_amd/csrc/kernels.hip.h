@@ -38,6 +38,8 @@ struct RState {
 struct FameCounters {
     u64 voter_evals;     // V  (swirld.py:247-254)
     u64 majority_evals;  // P2 (swirld.py:260)
+    u64 coin_votes;      // votes cast in coin rounds (swirld.py:267-272)
+    u64 coin_flips;      // ... of which taken from the signature bit (swirld.py:272)
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -1980,7 +1982,7 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
 #pragma unroll
     for (int j = 0; j < NW; ++j) V[j] = 0;
     int any_decided = 0;
-    u64 p2 = 0;
+    u64 p2 = 0, cvotes = 0, cflips = 0;
     for (int d = 1; r + d < R; ++d) {
         if (!__syncthreads_or(active)) break;
         const int rv = r + d;
@@ -2035,6 +2037,7 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
                         bitv = v;
                     } else {
                         bitv = sm ? v : (int)coin[wv];  // swirld.py:267-272
+                        if (active) { ++cvotes; cflips += !sm; }
                     }
                 }
                 acc |= (u64)bitv << ci;
@@ -2068,16 +2071,23 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
         newc[r] = 1;
         cons[r] = 1;
     }
-    {   // one atomic per workgroup
-        u64 t = p2;
+    {   // one atomic per workgroup and counter
+        u64 t = p2, tv = cvotes, tf = cflips;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) t += (u64)__shfl_xor((long long)t, off);
-        if ((cx & 63) == 0) s_p2[cx >> 6] = t;
+        for (int off = 32; off >= 1; off >>= 1) {
+            t += (u64)__shfl_xor((long long)t, off);
+            tv += (u64)__shfl_xor((long long)tv, off);
+            tf += (u64)__shfl_xor((long long)tf, off);
+        }
+        __shared__ u64 s_cv[16], s_cf[16];
+        if ((cx & 63) == 0) { s_p2[cx >> 6] = t; s_cv[cx >> 6] = tv; s_cf[cx >> 6] = tf; }
         __syncthreads();
         if (cx == 0) {
-            u64 tot = 0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_p2[w];
+            u64 tot = 0, totv = 0, totf = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot += s_p2[w]; totv += s_cv[w]; totf += s_cf[w]; }
             if (tot) atomicAdd(&fc->majority_evals, tot);
+            if (totv) atomicAdd(&fc->coin_votes, totv);
+            if (totf) atomicAdd(&fc->coin_flips, totf);
         }
     }
 }
@@ -2114,7 +2124,7 @@ k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const
 #pragma unroll
     for (int jj = 0; jj < NW; ++jj) V[jj] = 0;
     int any_decided = 0;
-    u64 p2 = 0;
+    u64 p2 = 0, cvotes = 0, cflips = 0;
     for (int d = 1; r + d < R; ++d) {
         if (!__syncthreads_or(active)) break;  // also: every read of the previous level is done
         const int rv = r + d;
@@ -2166,6 +2176,7 @@ k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const
                     bitv = v;
                 } else {
                     bitv = sm ? v : (int)coin[wv];  // swirld.py:267-272
+                    if (active) { ++cvotes; cflips += !sm; }
                 }
             }
             acc |= (u64)bitv << ci;
@@ -2212,16 +2223,23 @@ k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const
         newc[r] = 1;
         cons[r] = 1;
     }
-    {   // one atomic per workgroup
-        u64 t = p2;
+    {   // one atomic per workgroup and counter
+        u64 t = p2, tv = cvotes, tf = cflips;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) t += (u64)__shfl_xor((long long)t, off);
-        if ((tid & 63) == 0) s_p2[tid >> 6] = t;
+        for (int off = 32; off >= 1; off >>= 1) {
+            t += (u64)__shfl_xor((long long)t, off);
+            tv += (u64)__shfl_xor((long long)tv, off);
+            tf += (u64)__shfl_xor((long long)tf, off);
+        }
+        __shared__ u64 s_cv[16], s_cf[16];
+        if ((tid & 63) == 0) { s_p2[tid >> 6] = t; s_cv[tid >> 6] = tv; s_cf[tid >> 6] = tf; }
         __syncthreads();
         if (tid == 0) {
-            u64 tot = 0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_p2[w];
+            u64 tot = 0, totv = 0, totf = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot += s_p2[w]; totv += s_cv[w]; totf += s_cf[w]; }
             if (tot) atomicAdd(&fc->majority_evals, tot);
+            if (totv) atomicAdd(&fc->coin_votes, totv);
+            if (totf) atomicAdd(&fc->coin_flips, totf);
         }
     }
 }

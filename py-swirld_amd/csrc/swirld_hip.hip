@@ -1063,6 +1063,8 @@ int fame_launch(sw_ctx* c, int max_c, int part, int nparts, Span* sp_el) {
 void fame_counters(sw_ctx* c, const FameCounters& fc) {
     c->ctr.voter_evals += (int64_t)(fc.voter_evals - c->fc_seen.voter_evals);
     c->ctr.majority_evals += (int64_t)(fc.majority_evals - c->fc_seen.majority_evals);
+    c->ctr.coin_votes += (int64_t)(fc.coin_votes - c->fc_seen.coin_votes);
+    c->ctr.coin_flips += (int64_t)(fc.coin_flips - c->fc_seen.coin_flips);
     c->fc_seen = fc;
 }
 
@@ -1359,6 +1361,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_GRAPH")) c->use_graph = atoi(s) != 0;
     if (const char* s = getenv("SW_BAND_BLOCKS")) c->band_blocks = std::max(1, std::min(4096, atoi(s)));
     if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
+    if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
     if (const char* s = getenv("SW_FLOW_CFG")) c->flow_cfg = atoi(s);
@@ -1578,7 +1581,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     // ---- 2. allocations (still nothing committed)
     CHK(ensure_events(c, N0 + K));
     const size_t b4 = (size_t)K * sizeof(int32_t);
-    const bool stage = bulk && (t || sig64);
+    const bool stage = bulk && (t || sig64) && (size_t)K * 72 <= ((size_t)1 << 30);  // (beyond 1 GiB of payload: plain copies)
     if (stage) {
         const size_t need = (size_t)K * 72;
         if (c->payload_pending) { HIPCHK(c, hipEventSynchronize(c->ev_payload)); c->payload_pending = false; }

@@ -3,6 +3,7 @@ sizes, 1024 members, hot-member streams), started in background threads when the
 begins so that their single-core minutes overlap the rest of the suite (the oracle's C calls
 release the GIL; the GPU box has hundreds of host cores).  Never imported by the product."""
 import importlib
+import os
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -20,7 +21,25 @@ HEAVY = {
     "n1024_cliques": (1024, 100_000, 83, 1, 0.02, 0.0, None),
     # 13 of 256 members create 96 % of the events (long chains per round: gallop territory)
     "hot_256x400k": (256, 400_000, 84, 2, 0.95, 0.002, None),
+    # BASELINE.json configs[4]-style coin-round stress at a size the oracle can follow: 35 % of the
+    # members are 50x less active, elections run to distance 27 with ~46 k coin-round votes
+    # (swirld.py:267-272); batch and chunked call schedules
+    "coin_256x200k": (256, 200_000, 85, 2, 0.35, 0.02, None),
+    "coin_256x200k_chunked": (256, 200_000, 85, 2, 0.35, 0.02, 23_000),
 }
+
+
+if os.environ.get("SW_DRYRUN") == "1":
+    # tests/dryrun_heavy.py: the LOGIC of the heavy GPU tests on the CPU (oracle-backed Hashgraph), tiny sizes
+    HEAVY = {
+        "c3_256x1M": (16, 20000, 3, 0, 0.0, 0.0, None),
+        "n1024_uniform": (40, 9000, 81, 0, 0.0, 0.0, None),
+        "n1024_uniform_chunked": (40, 6000, 82, 0, 0.0, 0.0, 1700),
+        "n1024_cliques": (40, 9000, 83, 1, 0.02, 0.0, None),
+        "hot_256x400k": (32, 20000, 84, 2, 0.8, 0.01, None),
+        "coin_256x200k": (24, 12000, 85, 2, 0.35, 0.02, None),
+        "coin_256x200k_chunked": (24, 12000, 85, 2, 0.35, 0.02, 2300),
+    }
 
 
 class OracleRun:

@@ -201,6 +201,9 @@ def test_hip_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk):
     if chunk is None:
         assert c["voter_evals"] == co["voter_evals"]
         assert c["majority_evals"] == co["majority_evals"]
+        assert c["coin_votes"] == co["coin_votes"] and c["coin_flips"] == co["coin_flips"]
+        if n <= 4:
+            assert co["coin_flips"] > 0, "the 4-member cases must exercise coin rounds (swirld.py:267-272)"
     h.close()
 
 
