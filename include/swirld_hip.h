@@ -142,6 +142,24 @@ int sw_get_vote(sw_ctx* ctx, int rv, int mv, int rc, int mc, int8_t* out);
 int sw_num_ordered(sw_ctx* ctx, int64_t* out);
 int sw_get_transactions(sw_ctx* ctx, int64_t first, int64_t K, int32_t* out);
 
+/*
+ * Gossip side, from the device-resident state.
+ * sw_get_known_heights: what Node.sync puts into its request (swirld.py:125-126):
+ *   out[member] = height of the newest event of that member the (divided) event `head_event`
+ *   can see, -1 if none.
+ * sw_sync_diff: what Node.ask_sync answers (swirld.py:154-161): the events a peer that reported
+ *   known_height[member] (-1: member unknown to it) is missing, as chain position ranges
+ *   [pos_first[m], pos_end[m]) of every member's self-parent chain — the ancestors-or-self of
+ *   `head_event` above the peer's heights, the head always included.  Equals the reference's
+ *   height-pruned BFS as a SET whenever the heights come from a real can_see row; for arbitrary
+ *   heights it is a superset (a receiver drops what it cannot validate).
+ * sw_get_chain_events: the event indices at chain positions [p0, p1) of one member.
+ */
+int sw_get_known_heights(sw_ctx* ctx, int64_t head_event, int32_t* out);
+int sw_sync_diff(sw_ctx* ctx, int64_t head_event, const int32_t* known_height, int32_t* pos_first,
+                 int32_t* pos_end, int64_t* n_events);
+int sw_get_chain_events(sw_ctx* ctx, int member, int32_t p0, int32_t p1, int32_t* out);
+
 /* Exact work counters of the calls so far: used by bench.py's roofline. */
 typedef struct sw_counters {
     int64_t events_divided;      /* events through divide_rounds                          */

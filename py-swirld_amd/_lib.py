@@ -56,6 +56,9 @@ SIGNATURES = {
     "sw_get_consensus": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "sw_get_sees_mask": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_vote": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int8)]),
+    "sw_get_known_heights": (C.c_int, [_P, C.c_int64, _P]),
+    "sw_sync_diff": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.POINTER(C.c_int64)]),
+    "sw_get_chain_events": (C.c_int, [_P, C.c_int, C.c_int32, C.c_int32, _P]),
     "sw_num_ordered": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sw_get_transactions": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_counters": (C.c_int, [_P, C.POINTER(Counters)]),

@@ -2423,6 +2423,48 @@ k_order_sort(const int* __restrict__ acc_ev, const long long* __restrict__ acc_o
     if (__syncthreads_or(tie) && tid == 0) host_flag[ri] = 1;
 }
 
+// ---------------------------------------------------------------------------------
+// Gossip side: what a peer needs from this node, from the device-resident state.
+// k_known_heights: {member -> height of the newest event of that member my head can see}
+// (swirld.py:125-126: {c: height[h] for c, h in can_see[head].items()}); -1 = absent.
+// k_sync_diff: the events ask_sync sends (swirld.py:154-161) as per-member chain position ranges.
+// The reference walks back from the head, not descending into parents the asker reported as known
+// (height <= its reported height for that creator).  For heights reported from a real can_see row a
+// known event has only known ancestors, so the walk reaches exactly the ancestors-or-self of the
+// head that are unknown: on member m's chain the positions after the last one with height <=
+// known[m], up to the newest event of m the head sees; the head itself is always sent.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_known_heights(const int* __restrict__ L, const int* __restrict__ ht, int head, int npad, int* out) {
+    const int m = threadIdx.x;
+    const int k = L[(size_t)head * npad + m];
+    out[m] = k >= 0 ? ht[k] : -1;
+}
+
+__global__ void __launch_bounds__(1024)
+k_sync_diff(const int* __restrict__ L, const int* __restrict__ ht, const int* __restrict__ seq, const int* __restrict__ cr,
+            const int* __restrict__ chain_start, const int* __restrict__ chain_ev, const int* __restrict__ known,
+            int head, int npad, int* pos_first, int* pos_end) {
+    const int m = threadIdx.x;
+    const int seen = L[(size_t)head * npad + m];
+    int p0 = 0, p1 = 0;
+    if (seen >= 0) {
+        p1 = seq[seen] + 1;
+        const int h = known[m];
+        const int cs = chain_start[m];
+        int a = 0, b = p1;  // first position whose height exceeds the asker's (heights grow along a chain)
+        if (h >= 0)
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (ht[chain_ev[cs + mid]] > h) b = mid; else a = mid + 1;
+            }
+        p0 = a;
+        if (m == cr[head] && p0 >= p1) p0 = p1 - 1;  // the walk starts at the head whatever the asker knows
+    }
+    pos_first[m] = p0;
+    pos_end[m] = p1 > p0 ? p1 : p0;
+}
+
 __global__ void k_fill_i32(int* p, size_t n, int v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;

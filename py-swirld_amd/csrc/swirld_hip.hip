@@ -1976,6 +1976,58 @@ int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
     return SW_OK;
 }
 
+int sw_get_known_heights(sw_ctx* c, int64_t head_event, int32_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (head_event < 0 || head_event >= c->divided) return fail(c, SW_ERANGE, "head %lld is not a divided event", (long long)head_event);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_dag_h(c));  // heights on the device
+    const int np = c->npad;
+    CHK(dgrow(c, c->d_q, (size_t)3 * np, 0));
+    hipLaunchKernelGGL(k_known_heights, dim3(1), dim3(np), 0, c->stream, (const int*)c->d_L.p, (const int*)c->d_ht.p, (int)head_event, np, c->d_q.p);
+    c->ctr.kernel_launches++;
+    std::vector<int32_t> tmp(np);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_q.p, np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::copy(tmp.begin(), tmp.begin() + c->n, out);
+    return SW_OK;
+}
+
+int sw_sync_diff(sw_ctx* c, int64_t head_event, const int32_t* known_height, int32_t* pos_first, int32_t* pos_end, int64_t* n_events) {
+    if (!c || !known_height || !pos_first || !pos_end) return SW_EINVAL;
+    if (head_event < 0 || head_event >= c->divided) return fail(c, SW_ERANGE, "head %lld is not a divided event", (long long)head_event);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_dag_h(c));
+    const int np = c->npad, n = c->n;
+    CHK(dgrow(c, c->d_q, (size_t)3 * np, 0));
+    std::vector<int32_t> kn(np, -1), res((size_t)2 * np);
+    std::copy(known_height, known_height + n, kn.begin());
+    HIPCHK(c, hipMemcpyAsync(c->d_q.p, kn.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_sync_diff, dim3(1), dim3(np), 0, c->stream, (const int*)c->d_L.p, (const int*)c->d_ht.p, (const int*)c->d_seq.p,
+                       (const int*)c->d_cr.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, (const int*)c->d_q.p,
+                       (int)head_event, np, c->d_q.p + np, c->d_q.p + 2 * np);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipMemcpyAsync(res.data(), c->d_q.p + np, (size_t)2 * np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t tot = 0;
+    for (int m = 0; m < n; ++m) {
+        pos_first[m] = res[m];
+        pos_end[m] = res[(size_t)np + m];
+        tot += pos_end[m] - pos_first[m];
+    }
+    if (n_events) *n_events = tot;
+    return SW_OK;
+}
+
+int sw_get_chain_events(sw_ctx* c, int member, int32_t p0, int32_t p1, int32_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (member < 0 || member >= c->n || p0 < 0 || p1 < p0 || p1 > c->nev[member]) return fail(c, SW_ERANGE, "chain positions [%d, %d) of member %d", p0, p1, member);
+    if (p1 == p0) return SW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_chain_ev.p + c->chain_start_h[member] + p0, (size_t)(p1 - p0) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SW_OK;
+}
+
 int sw_num_ordered(sw_ctx* c, int64_t* out) {
     if (!c || !out) return SW_EINVAL;
     *out = (int64_t)c->transactions.size();

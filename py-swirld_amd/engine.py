@@ -155,6 +155,29 @@ class Hashgraph:
         self._chk(self._L.sw_get_vote(self._h, int(rv), int(mv), int(rc), int(mc), C.byref(v)))
         return int(v.value)
 
+    # ---- gossip side from device state (N4) ----
+    def known_heights(self, head_event):
+        """{member -> height of the newest event of that member `head_event` sees} as an array, -1 absent
+        (what Node.sync reports, swirld.py:125-126)."""
+        out = np.empty(self.n, np.int32)
+        self._chk(self._L.sw_get_known_heights(self._h, int(head_event), _p(out)))
+        return out
+
+    def sync_diff(self, head_event, known_height):
+        """Chain position ranges (first[m], end[m]) of the events a peer with these heights is missing
+        (what Node.ask_sync sends, swirld.py:154-161)."""
+        kn = np.ascontiguousarray(known_height, np.int32)
+        first = np.empty(self.n, np.int32)
+        end = np.empty(self.n, np.int32)
+        tot = C.c_int64()
+        self._chk(self._L.sw_sync_diff(self._h, int(head_event), _p(kn), _p(first), _p(end), C.byref(tot)))
+        return first, end, int(tot.value)
+
+    def chain_events(self, member, p0, p1):
+        out = np.empty(max(p1 - p0, 0), np.int32)
+        self._chk(self._L.sw_get_chain_events(self._h, int(member), int(p0), int(p1), _p(out)))
+        return out
+
     def transactions(self):
         n = C.c_int64()
         self._chk(self._L.sw_num_ordered(self._h, C.byref(n)))

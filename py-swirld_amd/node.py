@@ -196,6 +196,13 @@ class _VotesView(Mapping):
 
 
 class Node:
+    # ask_sync from the device-resident state (sw_sync_diff) instead of the reference's
+    # height-pruned BFS over Python dicts.  Same SET of events for honest askers; the reply dict is then
+    # filled member by member instead of in BFS order, which changes nothing for the receiver except the
+    # iteration order of a Python set (and with it the order concurrent events are added in) — so the
+    # default keeps the BFS, which makes whole simulations reproduce the reference event for event.
+    device_sync_diff = False
+
     def __init__(self, kp, network, n_nodes, stake, device=0):
         self.pk, self.sk = kp
         self.network = network  # {pk -> Node.ask_sync}
@@ -220,6 +227,7 @@ class Node:
         self._ids = []
         self._index = {}
         self._chain_head = {}  # {member pk -> its newest event in this view} (fork rejection)
+        self._chains = [[] for _ in range(n_nodes)]  # per member: its events in self-parent order (hashes)
         self._pending = []    # (creator, self_parent, other_parent, t, sig) not yet uploaded
         self._uploaded = 0
         self._divided = 0
@@ -289,13 +297,18 @@ class Node:
         self.height[h] = 1 + max(self.height[p] for p in ev.p) if ev.p else 0
         self._index[h] = len(self._ids)
         self._ids.append(h)
+        self._chains[self._mindex[ev.c]].append(h)
         sp, op = (self._index[ev.p[0]], self._index[ev.p[1]]) if ev.p else (-1, -1)
         self._pending.append((self._mindex[ev.c], sp, op, float(ev.t), ev.s))
 
     def _known_heights(self):
         """{member pk -> height of the newest event of that member my head can see}: what a
         peer needs to know to send only what I am missing (swirld.py:125-126)."""
-        return {pk: self.height[h] for pk, h in self.can_see[self.head].items()}
+        hd = self._index[self.head]
+        if hd >= self._divided:
+            raise KeyError(self.head)
+        kh = self._dev.known_heights(hd)  # one device call: heights of the can_see[head] entries
+        return {self._members[c]: int(v) for c, v in enumerate(kh) if v >= 0}
 
     def sync(self, pk, payload):
         """Pull-sync with `pk`; returns the new event ids in topological order
@@ -319,6 +332,18 @@ class Node:
         """Answer a sync request with every event the asker cannot know yet: walk back from
         my head, not descending below what the asker reported per member (swirld.py:148-161)."""
         asker_heights = loads(crypto.sign_open(info, pk))
+        if self.device_sync_diff and self._index[self.head] < self._divided:
+            known = np.full(self.n, -1, np.int32)
+            for creator, hgt in asker_heights.items():
+                c = self._mindex.get(creator)
+                if c is not None:
+                    known[c] = min(int(hgt), 0x7FFFFFFF) if hgt >= 0 else -1
+            first, end, _ = self._dev.sync_diff(self._index[self.head], known)
+            subset = {self.head: self.hg[self.head]}
+            for c in range(self.n):
+                for eid in self._chains[c][first[c]:end[c]]:
+                    subset[eid] = self.hg[eid]
+            return crypto.sign(dumps((self.head, subset)), self.sk)
 
         def missing_parents(u):
             for p in self.hg[u].p:

@@ -46,6 +46,11 @@ class OracleHashgraph:
     def famous(self, r0=0, r1=None):
         return self._o.famous_table(r0, r1)
 
+    def known_heights(self, head_event):
+        row = self._o.can_see[head_event]
+        ht = self._o.height
+        return np.where(row >= 0, ht[np.maximum(row, 0)], -1).astype(np.int32)
+
     def consensus(self, r0=0, r1=None):
         return self._o.consensus(r0, r1)
 
