@@ -886,6 +886,36 @@ __global__ void k_chain_scatter(const int* __restrict__ cr, const int* __restric
     cdesc[at] = make_int4(e, o, w, sp[e]);
 }
 
+// Ingest of a SMALL append (a Node's gossip step: a handful of events): one packed record per event,
+// one host-to-device copy, this one kernel — parent arrays, height, chain position, timestamp,
+// signature, coin bit, round = "not divided", chain pool entry, chain descriptor, chain length.
+struct SmallRec {
+    int cr, sp, op, seq, ht, at, w, pad;  // at = pool index of the event; w = creator(op) | (seq(op) & 63) << 10
+    double t;
+    unsigned char sig[64];
+};
+static_assert(sizeof(SmallRec) == 104, "packed ingest record");
+
+__global__ void k_ingest_small(const SmallRec* __restrict__ rec, int first, int K, int* cr, int* sp, int* op, int* seq, int* ht,
+                               double* t, unsigned char* sig, unsigned char* coin, int* round, int* chain_ev, int4* cdesc,
+                               int* chain_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const SmallRec r = rec[i];
+    const int e = first + i;
+    cr[e] = r.cr; sp[e] = r.sp; op[e] = r.op; seq[e] = r.seq; ht[e] = r.ht;
+    t[e] = r.t;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(rec[i].sig);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(sig + (size_t)e * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dst[k] = src[k];
+    coin[e] = r.sig[0] >> 7;  // swirld.py:272
+    round[e] = -1;
+    chain_ev[r.at] = e;
+    cdesc[r.at] = make_int4(e, r.op, r.w, r.sp);
+    atomicMax(&chain_cnt[r.cr], r.seq + 1);
+}
+
 // Ingest: the part of is_valid_event's parent check (swirld.py:104-108) that needs a lookup —
 // "the other-parent is by another member" — for a bulk append, on the device; err = smallest
 // offending event index (INT_MAX: none).  (Arity, order and the fork / same-creator test of the
@@ -930,6 +960,7 @@ struct LoopBufs {
                       // slot j (chain position cursor + j * stride); -1 = none
     int* gallop;      // [2][npad] window stride (bits 0-7; 1 = contiguous) and consecutive windows without
                       // a passing candidate (bits 8+) of the member in the current round
+    int* front;       // [npad] per member the last round r with lo[r][member] finite (-1 none): where the next call resumes
     u64* dbg;         // diagnostics (SW_DEBUG_CLOCKS=1): [iteration][32] wall-clock stamps, else null
 };
 
@@ -1175,6 +1206,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                 if (writer) {
                     lo[(size_t)(r + 1) * npad + c] = my_lo_next;
                     lopos[(size_t)(r + 1) * npad + c] = my_pos_next;
+                    B.front[c] = r + 1;
                 }
                 lr = my_lo_next;
                 start = my_pos_next;

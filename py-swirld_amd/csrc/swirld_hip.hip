@@ -53,6 +53,11 @@ struct sw_ctx {
     hipStream_t stream_io = nullptr;  // payload (timestamps, signatures) uploads of bulk appends
     hipEvent_t ev_payload = nullptr;  // ... and their completion (find_order / coin bits wait for it)
     bool payload_pending = false;
+    std::vector<int32_t> seq_h;     // chain position of every event (host mirror: small appends pack creator(op) | seq(op))
+    SmallRec* h_small = nullptr;    // pinned staging of small appends (one packed record per event)
+    size_t h_small_cap = 0;
+    hipEvent_t ev_small = nullptr;  // ... and the completion of its last upload
+    bool small_pending = false;
     char* h_pin = nullptr;          // pinned staging of bulk appends
     size_t h_pin_cap = 0;
     int max_height = 0;
@@ -96,11 +101,17 @@ struct sw_ctx {
     double stage_us[8] = {0};    // sw_divide_rounds host stages: sweeps enqueued, loop set-up, round loop, front rows, aux launches, final syncs
     int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
+    DBuf<int32_t> d_front;
+    DBuf<unsigned char> d_small;   // device copy of the packed records of the current small append
+    hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr;
+    std::vector<int32_t> divided_cnt;   // per member: events already divided (chain positions below `divided`)
+    std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;
-    std::vector<int32_t> front;       // per member: max r with lo[r][c] finite (-1 none)
+    std::vector<int32_t> front;       // per member: max r with lo[r][c] finite (-1 none); the device keeps it (d_front), the host mirror follows
+    std::vector<int32_t> front_dev;   // read-back buffer of d_front
     std::vector<int32_t> lo0_h;       // host copy of lo[0][.] (chain starts)
     std::vector<unsigned char> cons_h;  // host mirror of consensus
     int sw_dirty_from = 1;            // voter masks of rounds >= this must be (re)built
@@ -185,11 +196,13 @@ int dgrow(sw_ctx* c, DBuf<T>& b, size_t need, size_t keep) {
     T* q = nullptr;
     hipError_t e = hipMalloc((void**)&q, nc * sizeof(T));
     if (e != hipSuccess) return fail(c, SW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", nc * sizeof(T), hipGetErrorString(e));
-    if (keep && b.p) {
-        HIPCHK(c, hipMemcpyAsync(q, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (b.p) {
+        // the old buffer may still be in use on any of the context's streams (calls return without a
+        // host synchronisation): drain the device before it is copied and freed — reallocation is rare
+        HIPCHK(c, hipDeviceSynchronize());
+        if (keep) HIPCHK(c, hipMemcpy(q, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice));
+        (void)hipFree(b.p);
     }
-    if (b.p) (void)hipFree(b.p);
     b.p = q;
     b.cap = nc;
     return SW_OK;
@@ -345,48 +358,6 @@ int rebuild_chains(sw_ctx* c, const std::vector<int32_t>& cnt, int64_t n_events)
     HIPCHK(c, hipMemcpyAsync(c->d_chain_cnt.p, cntp.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (the staging vectors above are locals)
     return scatter_chains(c, 0, n_events);
-}
-
-// Small append: events [N0, N0 + K) with creators cr_new[] join their members' segments in place; a
-// full segment moves to the end of the pool, doubled (device-to-device).  O(K + members).
-int extend_chains(sw_ctx* c, int64_t N0, int64_t K, const int32_t* cr_new, const std::vector<int32_t>& cnt_after) {
-    const int np = c->npad, n = c->n;
-    std::vector<int32_t> before(cnt_after.begin(), cnt_after.begin() + n);
-    for (int64_t i = 0; i < K; ++i) before[cr_new[i]]--;
-    for (int m = 0; m < n; ++m) {
-        if (cnt_after[m] <= c->chain_cap[m]) continue;
-        int32_t ncap = std::max(16, 2 * c->chain_cap[m]);
-        while (ncap < cnt_after[m]) ncap *= 2;
-        if (c->pool_used + ncap > 0x7fffffff) return fail(c, SW_ERANGE, "chain pool exceeds 2^31 entries");
-        const int64_t noff = c->pool_used;
-        CHK(dgrow(c, c->d_chain_ev, (size_t)(noff + ncap) * 2, (size_t)c->pool_used));
-        CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, (size_t)c->pool_used));
-        if (before[m]) {
-            HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p + noff, c->d_chain_ev.p + c->chain_start_h[m], (size_t)before[m] * sizeof(int32_t),
-                                     hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->d_cdesc.p + noff, c->d_cdesc.p + c->chain_start_h[m], (size_t)before[m] * sizeof(int4),
-                                     hipMemcpyDeviceToDevice, c->stream));
-        }
-        if (c->pool_h_valid) {
-            c->chain_ev_h.resize((size_t)(noff + ncap), -1);
-            std::copy(c->chain_ev_h.begin() + c->chain_start_h[m], c->chain_ev_h.begin() + c->chain_start_h[m] + before[m],
-                      c->chain_ev_h.begin() + noff);
-        }
-        c->chain_start_h[m] = (int32_t)noff;
-        c->chain_cap[m] = ncap;
-        c->pool_used = noff + ncap;
-    }
-    if (c->pool_h_valid) {
-        if (c->chain_ev_h.size() < (size_t)c->pool_used) c->chain_ev_h.resize((size_t)c->pool_used, -1);
-        std::vector<int32_t> fill(before);
-        for (int64_t i = 0; i < K; ++i) { const int m = cr_new[i]; c->chain_ev_h[(size_t)c->chain_start_h[m] + fill[m]++] = (int32_t)(N0 + i); }
-    }
-    std::vector<int32_t> cntp(np, 0);
-    std::copy(cnt_after.begin(), cnt_after.begin() + n, cntp.begin());
-    HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, c->chain_start_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_chain_cnt.p, cntp.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return scatter_chains(c, N0, K);
 }
 
 // ---- lazily fetched host mirrors: the device arrays are the source of truth -------------------
@@ -584,6 +555,7 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.force = c->d_force.p;
     B.cand = c->d_cand.p;
     B.gallop = c->d_gallop.p;
+    B.front = c->d_front.p;
     B.dbg = c->d_dbg;
     return B;
 }
@@ -695,8 +667,12 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr, c->profiling ? &resolve_spans : nullptr));
         launched += shot;
         HIPCHK(c, hipGetLastError());
+        int ferr = 0;
         HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->front_dev.data(), c->d_front.p, np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&ferr, c->d_flow_err, sizeof ferr, hipMemcpyDeviceToHost, c->stream));  // (the sweep of this sub-batch is complete)
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (ferr) return fail(c, SW_EIO, "can_see sweep gave up polling (code %d): internal protocol error", ferr);
         if (st.err) return fail(c, SW_ERANGE, "round table capacity exceeded (internal)");
         if (st.done) break;
         // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
@@ -855,17 +831,28 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->cs_events.push_back(e);
     }
-    // ---- enqueue every can_see sweep on its own stream
+    // ---- enqueue every can_see sweep on its own stream (behind whatever the main stream still has in
+    // flight: a small append returns without a host synchronisation)
     hipStream_t cs = c->stream_cs;
+    HIPCHK(c, hipEventRecord(c->ev_main_mark, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(cs, c->ev_main_mark, 0));
     hipEvent_t cs_t0 = nullptr, cs_t1 = nullptr;
     if (c->profiling) { cs_t0 = next_event(c); cs_t1 = next_event(c); (void)hipEventRecord(cs_t0, cs); }
     std::vector<Span> cansee_spans;
     if (c->profiling) { c->tm.resolve_ms = 0.f; c->tm.resolve_launches = 0; }
-    // chain positions of the cuts: bounds[i][m] = events of member m below cut[i] (device binary searches)
-    std::vector<int32_t> bounds_h((size_t)(S + 1) * np);
-    {
+    // chain positions of the cuts: bounds[i][m] = events of member m below cut[i].  One cut pair that
+    // ends at the last appended event (a Node's call) is known on the host: chain lengths at the last
+    // divide and now.  Otherwise device binary searches over the chain pool.
+    std::vector<int32_t>& bounds_h = c->bounds_stage;
+    bounds_h.resize((size_t)(S + 1) * np);
+    CHK(dgrow(c, c->d_bounds, (size_t)(S + 1) * np, 0));
+    if (S == 1 && first + K == c->N) {
+        std::copy(c->divided_cnt.begin(), c->divided_cnt.end(), bounds_h.begin());
+        std::fill(bounds_h.begin() + np, bounds_h.end(), 0);
+        std::copy(c->nev.begin(), c->nev.end(), bounds_h.begin() + np);
+        HIPCHK(c, hipMemcpyAsync(c->d_bounds.p, bounds_h.data(), bounds_h.size() * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+    } else {
         CHK(dgrow(c, c->d_cuts, S + 1, 0));
-        CHK(dgrow(c, c->d_bounds, (size_t)(S + 1) * np, 0));
         std::vector<long long> cuts_ll(cut.begin(), cut.end());
         HIPCHK(c, hipMemcpyAsync(c->d_cuts.p, cuts_ll.data(), (S + 1) * sizeof(long long), hipMemcpyHostToDevice, cs));
         hipLaunchKernelGGL(k_chain_bounds, dim3(S + 1), dim3(np), 0, cs, (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p,
@@ -927,8 +914,11 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         if (r_start == 0x7fffffff) r_start = std::max(c->R - 1, 0);
         r_min = std::min(r_min, r_start);
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i], 0));
-        if (row0_dirty)
+        if (row0_dirty) {
             HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            std::copy(c->front.begin(), c->front.end(), c->front_dev.begin());
+            HIPCHK(c, hipMemcpyAsync(c->d_front.p, c->front_dev.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        }
         HIPCHK(c, hipMemcpyAsync(c->d_chain_len.p, clen.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         clk.mark(&c->stage_us[1]);
         const bool dbg_t = c->debug_timing && K >= 65536;
@@ -946,16 +936,9 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                     i, (long long)(cut[i + 1] - cut[i]), w, l, (long long)its, its ? l * 1e3 / (double)its : 0.0);
         }
         clk.mark(&c->stage_us[2]);
-        // host mirror of the per-member front round
+        // host mirror of the per-member front round (kept by the resolve kernel, read back with the loop state)
         const int R = c->R;
-        std::vector<int32_t> rows((size_t)std::max(R - r_start, 0) * np);
-        if (!rows.empty()) {
-            HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_lo.p + (size_t)r_start * np, rows.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
-        for (int m = 0; m < n; ++m)
-            for (int r = R - 1; r >= r_start; --r)
-                if (rows[(size_t)(r - r_start) * np + m] != SW_INF) { c->front[m] = std::max(c->front[m], r); break; }
+        for (int m = 0; m < n; ++m) c->front[m] = std::max(c->front[m], c->front_dev[m]);
         clen_prev.swap(clen);
         clk.mark(&c->stage_us[3]);
         // The rounds of every event below `limit` are final now (later sub-batches only add lo
@@ -984,16 +967,21 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     const int R = c->R;
     hipEvent_t fin_t1 = nullptr;
     if (c->profiling) { fin_t1 = next_event(c); (void)hipEventRecord(fin_t1, c->stream_aux); }
-    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+    // Everything later calls enqueue goes to the main stream (getters, decide_fame, find_order): it
+    // waits for the other two streams ON THE DEVICE; the host returns without a synchronisation
+    // (a Node makes one such call per gossip step — every host sync costs it ~15 us).
+    HIPCHK(c, hipEventRecord(c->ev_aux_done, c->stream_aux));
+    HIPCHK(c, hipEventRecord(c->ev_cs_done, c->stream_cs));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_cs_done, 0));
     span_end(c, sp_total);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream_cs));
-    HIPCHK(c, hipGetLastError());
-    if (flow) {
-        int ferr = 0;
-        HIPCHK(c, hipMemcpy(&ferr, c->d_flow_err, sizeof ferr, hipMemcpyDeviceToHost));
-        if (ferr) return fail(c, SW_EIO, "can_see sweep gave up polling (code %d): internal protocol error", ferr);
+    if (c->profiling || c->debug_timing) {
+        HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream_cs));
     }
+    HIPCHK(c, hipGetLastError());
+    std::copy(bounds_h.begin() + (size_t)S * np, bounds_h.begin() + (size_t)(S + 1) * np, c->divided_cnt.begin());
     clk.mark(&c->stage_us[5]);
     c->sw_dirty_from = std::max(R, 1);  // voter masks are up to date
     if (first + K == c->N) std::copy(c->head.begin(), c->head.end(), c->divided_head.begin());
@@ -1348,6 +1336,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->head.assign(n_members, -1);
     c->first_ev.assign(n_members, -1);
     c->front.assign(n_members, -1);
+    c->front_dev.assign(c->npad, -1);
     c->divided_head.assign(c->npad, -1);
     c->ord_pos.assign(n_members, 0);
     c->lo0_h.assign(c->npad, SW_INF);
@@ -1412,6 +1401,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
             CHIP(hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking));
         }
         CHIP(hipEventCreateWithFlags(&c->ev_payload, hipEventDisableTiming));
+        CHIP(hipEventCreateWithFlags(&c->ev_small, hipEventDisableTiming));
     }
     CHIP(hipMalloc((void**)&c->d_state, 2 * sizeof(RState)));
     CHIP(hipMemset(c->d_state, 0, 2 * sizeof(RState)));
@@ -1435,6 +1425,12 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
     CCHK(dgrow(c, c->d_cand, (size_t)2 * np * 64, 0));
     CCHK(dgrow(c, c->d_gallop, 2 * np, 0));
+    CCHK(dgrow(c, c->d_front, np, 0));
+    CCHK(fill_i32(c, c->d_front.p, np, -1));
+    c->divided_cnt.assign(np, 0);
+    CHIP(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
+    CHIP(hipEventCreateWithFlags(&c->ev_cs_done, hipEventDisableTiming));
+    CHIP(hipEventCreateWithFlags(&c->ev_main_mark, hipEventDisableTiming));
     CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_chain_start, np, 0));
@@ -1471,7 +1467,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
 int sw_destroy(sw_ctx* c) {
     if (!c) return SW_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     if (c->debug_timing && c->d_flow_dbg) {
         u64 d[8] = {0};
         (void)hipMemcpy(d, c->d_flow_dbg, sizeof d, hipMemcpyDeviceToHost);
@@ -1492,7 +1488,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
-    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_front); dfree(c->d_small); dfree(c->d_Mb);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_fc) (void)hipFree(c->d_fc);
     if (c->d_err) (void)hipFree(c->d_err);
@@ -1507,7 +1503,12 @@ int sw_destroy(sw_ctx* c) {
     for (auto e : c->cs_events) (void)hipEventDestroy(e);
     if (c->stream_io) { (void)hipStreamSynchronize(c->stream_io); (void)hipStreamDestroy(c->stream_io); }
     if (c->ev_payload) (void)hipEventDestroy(c->ev_payload);
+    if (c->ev_aux_done) (void)hipEventDestroy(c->ev_aux_done);
+    if (c->ev_cs_done) (void)hipEventDestroy(c->ev_cs_done);
+    if (c->ev_main_mark) (void)hipEventDestroy(c->ev_main_mark);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->ev_small) (void)hipEventDestroy(c->ev_small);
     if (c->stream_cs) (void)hipStreamDestroy(c->stream_cs);
     if (c->stream_aux) (void)hipStreamDestroy(c->stream_aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1536,6 +1537,106 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
         if (a1 > a0) th.emplace_back([=] { memcpy((char*)dst + a0, (const char*)src + a0, a1 - a0); });
     }
     for (auto& t : th) t.join();
+}
+
+// A Node's gossip step appends a handful of events: one packed record per event in pinned memory,
+// ONE host-to-device copy, ONE kernel (k_ingest_small), no host synchronisation.  The batch has been
+// validated; the per-member tables of the caller (head_t, nev_t, first_t) are committed here.
+static int append_small(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t* self_parent, const int32_t* other_parent,
+                        const double* t, const uint8_t* sig64, const std::vector<int32_t>& seq, std::vector<int32_t>& head_t,
+                        std::vector<int32_t>& nev_t, std::vector<int32_t>& first_t) {
+    const int64_t N0 = c->N;
+    const int n = c->n, np = c->npad;
+    CHK(ensure_dag_h(c));  // parents' heights (complete already unless a bulk append came before)
+    if ((size_t)K > c->h_small_cap) {
+        if (c->small_pending) { HIPCHK(c, hipEventSynchronize(c->ev_small)); c->small_pending = false; }
+        if (c->h_small) (void)hipHostFree(c->h_small);
+        c->h_small = nullptr; c->h_small_cap = 0;
+        const size_t cap = std::max<size_t>(256, (size_t)K * 2);
+        if (hipHostMalloc((void**)&c->h_small, cap * sizeof(SmallRec), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, SW_ENOMEM, "hipHostMalloc for the small-append staging buffer failed");
+        }
+        c->h_small_cap = cap;
+    }
+    // ---- segments that overflow move to the end of the pool, doubled (device-to-device)
+    bool moved = false;
+    for (int m = 0; m < n; ++m) {
+        if (nev_t[m] <= c->chain_cap[m]) continue;
+        int32_t ncap = std::max(16, 2 * c->chain_cap[m]);
+        while (ncap < nev_t[m]) ncap *= 2;
+        if (c->pool_used + ncap > 0x7fffffff) return fail(c, SW_ERANGE, "chain pool exceeds 2^31 entries");
+        const int64_t noff = c->pool_used;
+        const int32_t before = c->nev[m];
+        CHK(dgrow(c, c->d_chain_ev, (size_t)(noff + ncap) * 2, (size_t)c->pool_used));
+        CHK(dgrow(c, c->d_cdesc, c->d_chain_ev.cap, (size_t)c->pool_used));
+        if (before) {
+            HIPCHK(c, hipMemcpyAsync(c->d_chain_ev.p + noff, c->d_chain_ev.p + c->chain_start_h[m], (size_t)before * sizeof(int32_t),
+                                     hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_cdesc.p + noff, c->d_cdesc.p + c->chain_start_h[m], (size_t)before * sizeof(int4),
+                                     hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (c->pool_h_valid) {
+            c->chain_ev_h.resize((size_t)(noff + ncap), -1);
+            std::copy(c->chain_ev_h.begin() + c->chain_start_h[m], c->chain_ev_h.begin() + c->chain_start_h[m] + before, c->chain_ev_h.begin() + noff);
+        }
+        c->chain_start_h[m] = (int32_t)noff;
+        c->chain_cap[m] = ncap;
+        c->pool_used = noff + ncap;
+        moved = true;
+    }
+    if (moved) {
+        HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, c->chain_start_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (rare; keeps the host table free to change)
+    }
+    // ---- packed records
+    if (c->small_pending) { HIPCHK(c, hipEventSynchronize(c->ev_small)); c->small_pending = false; }
+    const bool dag_complete = (int64_t)c->sp.size() == N0;  // always, after ensure_dag_h
+    if (!dag_complete) return fail(c, SW_EIO, "host mirror of the hashgraph is incomplete (internal)");
+    c->cr.reserve(N0 + K); c->sp.reserve(N0 + K); c->op.reserve(N0 + K); c->ht.reserve(N0 + K); c->seq_h.reserve(N0 + K);
+    c->blk_hmin.resize((size_t)((N0 + K + 4095) >> 12), 0x7fffffff);
+    c->blk_hmax.resize((size_t)((N0 + K + 4095) >> 12), -1);
+    const bool sig_complete = (int64_t)(c->sig_h.size() / 64) == N0;
+    if (sig_complete) c->sig_h.resize((size_t)(N0 + K) * 64);
+    if (c->pool_h_valid && c->chain_ev_h.size() < (size_t)c->pool_used) c->chain_ev_h.resize((size_t)c->pool_used, -1);
+    for (int64_t i = 0; i < K; ++i) {
+        const int64_t e = N0 + i;
+        SmallRec& r = c->h_small[i];
+        const int32_t m = creator[i], s_ = self_parent[i], o_ = other_parent[i];
+        r.cr = m; r.sp = s_; r.op = o_; r.seq = seq[i];
+        const int32_t h = s_ < 0 ? 0 : std::max(c->ht[s_], c->ht[o_]) + 1;  // swirld.py:117-120 (parents are earlier: already mirrored)
+        r.ht = h;
+        r.at = c->chain_start_h[m] + seq[i];
+        r.w = o_ < 0 ? 0 : (c->cr[o_] | ((c->seq_h[o_] & 63) << 10));
+        r.pad = 0;
+        r.t = t ? t[i] : 0.0;
+        if (sig64) memcpy(r.sig, sig64 + 64 * i, 64); else memset(r.sig, 0, 64);
+        // host mirrors (a later event of this batch may have this one as a parent)
+        c->cr.push_back(m); c->sp.push_back(s_); c->op.push_back(o_); c->ht.push_back(h); c->seq_h.push_back(seq[i]);
+        c->max_height = std::max(c->max_height, h);
+        c->blk_hmin[e >> 12] = std::min(c->blk_hmin[e >> 12], h);
+        c->blk_hmax[e >> 12] = std::max(c->blk_hmax[e >> 12], h);
+        if (sig_complete) memcpy(c->sig_h.data() + (size_t)e * 64, r.sig, 64);
+        if (c->pool_h_valid) c->chain_ev_h[(size_t)r.at] = (int32_t)e;
+    }
+    // (from here on the host tables are committed; a device failure poisons the context)
+    c->head.swap(head_t);
+    c->first_ev.swap(first_t);
+    c->nev.swap(nev_t);
+    c->N = N0 + K;
+    CHK(dgrow(c, c->d_small, (size_t)c->h_small_cap * sizeof(SmallRec), 0));
+    hipError_t e1 = hipMemcpyAsync(c->d_small.p, c->h_small, (size_t)K * sizeof(SmallRec), hipMemcpyHostToDevice, c->stream);
+    if (e1 == hipSuccess) {
+        hipLaunchKernelGGL(k_ingest_small, dim3((unsigned)((K + 127) / 128)), dim3(128), 0, c->stream, (const SmallRec*)c->d_small.p, (int)N0, (int)K,
+                           c->d_cr.p, c->d_sp.p, c->d_op.p, c->d_seq.p, c->d_ht.p, c->d_t.p, c->d_sig.p, c->d_coin.p, c->d_round.p,
+                           c->d_chain_ev.p, c->d_cdesc.p, c->d_chain_cnt.p);
+        c->ctr.kernel_launches++;
+        e1 = hipGetLastError();
+    }
+    if (e1 == hipSuccess) e1 = hipEventRecord(c->ev_small, c->stream);
+    if (e1 != hipSuccess) { c->poisoned = true; return fail(c, SW_EIO, "small append: %s", hipGetErrorString(e1)); }
+    c->small_pending = true;
+    return SW_OK;
 }
 
 int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t* self_parent,
@@ -1580,6 +1681,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     HIPCHK(c, hipSetDevice(c->device));
     // ---- 2. allocations (still nothing committed)
     CHK(ensure_events(c, N0 + K));
+    if (!bulk) return append_small(c, K, creator, self_parent, other_parent, t, sig64, seq, head_t, nev_t, first_t);
     const size_t b4 = (size_t)K * sizeof(int32_t);
     const bool stage = bulk && (t || sig64) && (size_t)K * 72 <= ((size_t)1 << 30);  // (beyond 1 GiB of payload: plain copies)
     if (stage) {
@@ -1587,6 +1689,8 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         if (c->payload_pending) { HIPCHK(c, hipEventSynchronize(c->ev_payload)); c->payload_pending = false; }
         if (need > c->h_pin_cap) {
             if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->ev_small) (void)hipEventDestroy(c->ev_small);
             c->h_pin = nullptr; c->h_pin_cap = 0;
             if (hipHostMalloc((void**)&c->h_pin, need, hipHostMallocDefault) != hipSuccess) {
                 (void)hipGetLastError();
@@ -1621,6 +1725,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
 #define PHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->poisoned = true; \
         return fail(c, SW_EIO, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
     c->cr.insert(c->cr.end(), creator, creator + K);
+    c->seq_h.insert(c->seq_h.end(), seq.begin(), seq.end());
     // the lazily fetched mirrors stay complete when they were complete (a Node appends a few events per
     // call); after a bulk append they are refilled from the device on demand
     if (!bulk && (int64_t)c->sp.size() == N0) {
@@ -1664,8 +1769,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     if (stage) { PHIP(hipEventRecord(c->ev_payload, ps)); c->payload_pending = true; }
     PHIP(hipMemsetAsync(c->d_round.p + N0, 0xff, b4, c->stream));
     // per-member chain pool + chain descriptors: part of the ingest-time layout of the hashgraph store
-    if (bulk) PCHK(rebuild_chains(c, nev_t, c->N));
-    else PCHK(extend_chains(c, N0, K, creator, nev_t));
+    PCHK(rebuild_chains(c, nev_t, c->N));
     c->nev.swap(nev_t);
     PHIP(hipStreamSynchronize(c->stream));  // caller buffers may be released on return (bulk payload: staged copy)
 #undef PCHK
@@ -1759,6 +1863,8 @@ int sw_commit_fame(sw_ctx* c, const int8_t* famous, const uint8_t* decided, int 
 int sw_rewind(sw_ctx* c) {
     if (!c) return SW_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream_cs));   // (calls return without a host synchronisation)
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
     const size_t rows = (size_t)c->Rcap * c->npad;
     CHK(fill_i32(c, c->d_lo.p, rows, SW_INF));
     CHK(fill_i32(c, c->d_lopos.p, rows, 0));
@@ -1772,8 +1878,10 @@ int sw_rewind(sw_ctx* c) {
     CHK(fill_i32(c, c->d_evalround.p, 2 * c->npad, -1));
     CHK(fill_i32(c, c->d_evalpos.p, 2 * c->npad, 0));
     if (c->N) HIPCHK(c, hipMemsetAsync(c->d_round.p, 0xff, (size_t)c->N * sizeof(int32_t), c->stream));
+    CHK(fill_i32(c, c->d_front.p, c->npad, -1));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::fill(c->front.begin(), c->front.end(), -1);
+    std::fill(c->divided_cnt.begin(), c->divided_cnt.end(), 0);
     std::fill(c->divided_head.begin(), c->divided_head.end(), -1);
     std::fill(c->lo0_h.begin(), c->lo0_h.end(), SW_INF);
     std::fill(c->cons_h.begin(), c->cons_h.end(), 0);
@@ -1789,7 +1897,7 @@ int sw_reset(sw_ctx* c) {
     if (!c) return SW_EINVAL;
     CHK(sw_rewind(c));
     // forget the events as well; device storage (and the launch graphs keyed on it) stays
-    c->cr.clear(); c->sp.clear(); c->op.clear(); c->ht.clear();
+    c->cr.clear(); c->sp.clear(); c->op.clear(); c->ht.clear(); c->seq_h.clear();
     std::fill(c->head.begin(), c->head.end(), -1);
     std::fill(c->first_ev.begin(), c->first_ev.end(), -1);
     std::fill(c->nev.begin(), c->nev.end(), 0);
