@@ -1689,8 +1689,6 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         if (c->payload_pending) { HIPCHK(c, hipEventSynchronize(c->ev_payload)); c->payload_pending = false; }
         if (need > c->h_pin_cap) {
             if (c->h_pin) (void)hipHostFree(c->h_pin);
-    if (c->h_small) (void)hipHostFree(c->h_small);
-    if (c->ev_small) (void)hipEventDestroy(c->ev_small);
             c->h_pin = nullptr; c->h_pin_cap = 0;
             if (hipHostMalloc((void**)&c->h_pin, need, hipHostMallocDefault) != hipSuccess) {
                 (void)hipGetLastError();
