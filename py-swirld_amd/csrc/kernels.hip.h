@@ -985,7 +985,9 @@ __device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v));
 // Start of a round-loop run: the loop state and the per-member buffers in ONE launch (a small
 // call would otherwise pay five separate copies / fills, ~10 us each).
 __global__ void __launch_bounds__(1024)
-k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap) {
+k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len) {
+    // chain lengths visible to this run = the sub-batch's row of the cut table (already on the device)
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) chain_len[i] = visible_len[i];
     if (threadIdx.x == 0) {
         RState t{};
         t.r = r_start;

@@ -101,15 +101,22 @@ struct sw_ctx {
     double stage_us[8] = {0};    // sw_divide_rounds host stages: sweeps enqueued, loop set-up, round loop, front rows, aux launches, final syncs
     int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
-    DBuf<int32_t> d_front;
+    struct { int32_t* p = nullptr; } d_front;   // inside d_rb
     DBuf<unsigned char> d_small;   // device copy of the packed records of the current small append
     hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr;
     std::vector<int32_t> divided_cnt;   // per member: events already divided (chain positions below `divided`)
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
+    // one device block read back with ONE copy per round-loop shot: loop state (x2), sweep error flag, per-member
+    // front rounds; and its pinned host mirror
+    unsigned char* d_rb = nullptr;
+    unsigned char* h_rb = nullptr;
+    size_t rb_bytes = 0;
     RState* d_state = nullptr;
-    FameCounters* d_fc = nullptr;
+    FameCounters* d_fc = nullptr;   // header of d_newc: the fame counters travel with the new_c flags in one copy
+    unsigned char* h_fame = nullptr;  // pinned: [FameCounters][newc flags]
+    size_t h_fame_cap = 0;
     std::vector<int32_t> front;       // per member: max r with lo[r][c] finite (-1 none); the device keeps it (d_front), the host mirror follows
     std::vector<int32_t> front_dev;   // read-back buffer of d_front
     std::vector<int32_t> lo0_h;       // host copy of lo[0][.] (chain starts)
@@ -263,7 +270,15 @@ int ensure_rounds(sw_ctx* c, int need) {
     CHK(dgrow(c, c->d_dec_call, (size_t)nc * np, keep));
     CHK(dgrow(c, c->d_dec_by, (size_t)nc * np, keep));
     CHK(dgrow(c, c->d_cons, nc, c->Rcap));
-    CHK(dgrow(c, c->d_newc, nc, 0));
+    CHK(dgrow(c, c->d_newc, (size_t)nc + sizeof(FameCounters), c->d_newc.p ? sizeof(FameCounters) : 0));
+    if (!c->d_fc) HIPCHK(c, hipMemset(c->d_newc.p, 0, sizeof(FameCounters)));
+    c->d_fc = reinterpret_cast<FameCounters*>(c->d_newc.p);
+    if ((size_t)nc + sizeof(FameCounters) > c->h_fame_cap) {
+        if (c->h_fame) (void)hipHostFree(c->h_fame);
+        c->h_fame = nullptr;
+        c->h_fame_cap = (size_t)nc + sizeof(FameCounters);
+        if (hipHostMalloc((void**)&c->h_fame, c->h_fame_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->h_fame_cap = 0; return fail(c, SW_ENOMEM, "hipHostMalloc for the fame read-back failed"); }
+    }
     const size_t fresh = (size_t)(nc - c->Rcap) * np;
     CHK(fill_i32(c, c->d_lo.p + keep, fresh, SW_INF));
     CHK(fill_i32(c, c->d_lopos.p + keep, fresh, 0));
@@ -606,7 +621,8 @@ constexpr int kGraphSizes[3] = {24, 8, 2};
 
 template <int NW>
 int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, std::vector<Span>* resolve_spans = nullptr) {
-    if (!c->use_graph || tally_spans) {
+    // short shots (a Node's small calls): plain launches — the first hipGraphLaunch of a call costs ~200 us
+    if (!c->use_graph || tally_spans || n_iters <= 8) {
         for (int it = 0; it < n_iters; ++it) enqueue_iteration<NW>(c, it & 1, tally_spans, resolve_spans);
         return SW_OK;
     }
@@ -642,10 +658,10 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
 }
 
 template <int NW>
-int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, float* tally_ms_out, int* tally_launches_out) {
+int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, const int32_t* visible_len, float* tally_ms_out, int* tally_launches_out) {
     const int np = c->npad, K = c->K;
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
-                       (int)limit, c->NEARCAP);
+                       (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p);
     c->ctr.kernel_launches++;
     std::vector<Span> tally_spans, resolve_spans;
     RState st{};
@@ -667,11 +683,14 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr, c->profiling ? &resolve_spans : nullptr));
         launched += shot;
         HIPCHK(c, hipGetLastError());
-        int ferr = 0;
-        HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->front_dev.data(), c->d_front.p, np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&ferr, c->d_flow_err, sizeof ferr, hipMemcpyDeviceToHost, c->stream));  // (the sweep of this sub-batch is complete)
+        // loop state, sweep error flag (the sweep of this sub-batch is complete) and the members' front
+        // rounds: ONE copy into pinned memory
+        HIPCHK(c, hipMemcpyAsync(c->h_rb, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(&st, c->h_rb, sizeof st);
+        int ferr = 0;
+        memcpy(&ferr, c->h_rb + 2 * sizeof(RState), sizeof ferr);
+        memcpy(c->front_dev.data(), c->h_rb + 256, np * sizeof(int32_t));
         if (ferr) return fail(c, SW_EIO, "can_see sweep gave up polling (code %d): internal protocol error", ferr);
         if (st.err) return fail(c, SW_ERANGE, "round table capacity exceeded (internal)");
         if (st.done) break;
@@ -919,14 +938,13 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             std::copy(c->front.begin(), c->front.end(), c->front_dev.begin());
             HIPCHK(c, hipMemcpyAsync(c->d_front.p, c->front_dev.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_chain_len.p, clen.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         clk.mark(&c->stage_us[1]);
         const bool dbg_t = c->debug_timing && K >= 65536;
         const auto dbg_t0 = std::chrono::steady_clock::now();
         const int64_t dbg_it0 = c->ctr.round_iterations;
         if (dbg_t) (void)hipStreamSynchronize(c->stream);  // separates "waiting for the sweep" from the loop itself
         const auto dbg_t1 = std::chrono::steady_clock::now();
-        CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], &tally_ms, &tally_launches));
+        CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], c->d_bounds.p + (size_t)(i + 1) * np, &tally_ms, &tally_launches));
         if (dbg_t) {
             const auto dbg_t2 = std::chrono::steady_clock::now();
             const double w = std::chrono::duration<double, std::milli>(dbg_t1 - dbg_t0).count();
@@ -1021,14 +1039,14 @@ int fame_launch(sw_ctx* c, int max_c, int part, int nparts, Span* sp_el) {
     const uint32_t tot2 = 2u * c->tot;
     if (c->sw_dirty_from < R || R > c->Sw_rows) CHK(launch_voter_masks<NW>(c, std::min(c->sw_dirty_from, R), R, c->stream));
     c->sw_dirty_from = std::max(R, 1);
-    HIPCHK(c, hipMemsetAsync(c->d_newc.p, 0, R, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_newc.p + sizeof(FameCounters), 0, R, c->stream));
     const int nblk = R - max_c - part > 0 ? (R - max_c - part + nparts - 1) / nparts : 0;
     const int call_idx = (int)c->fame_calls.size();
     if (sp_el) *sp_el = span_begin(c);
     if (nblk > 0) {
         bool split_done = false;
 #define SW_ELECT_ARGS (const int*)c->d_wit.p, (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p, \
-                      tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p, c->d_fc, c->d_dec_call.p, c->d_dec_by.p, call_idx, part, nparts
+                      tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p + sizeof(FameCounters), c->d_fc, c->d_dec_call.p, c->d_dec_by.p, call_idx, part, nparts
         if constexpr (NW >= 2 && NW <= 4) {  // NW threads per candidate (see k_elections_split): npad * NW <= 1024
             if (c->elect_impl == 1) {
                 if (c->unit_stake) hipLaunchKernelGGL((k_elections_split<NW, true>), dim3(nblk), dim3(np * NW), 0, c->stream, SW_ELECT_ARGS);
@@ -1063,12 +1081,13 @@ int do_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     Span sp = span_begin(c), sp_el{};
     const int max_c = first_undecided_round(c);
     CHK(fame_launch<NW>(c, max_c, 0, 1, &sp_el));
-    std::vector<unsigned char> newc(R);
-    FameCounters fc{};
-    HIPCHK(c, hipMemcpyAsync(newc.data(), c->d_newc.p, R, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&fc, c->d_fc, sizeof fc, hipMemcpyDeviceToHost, c->stream));
+    // fame counters + new_c flags: one copy into pinned memory
+    HIPCHK(c, hipMemcpyAsync(c->h_fame, c->d_newc.p, sizeof(FameCounters) + (size_t)R, hipMemcpyDeviceToHost, c->stream));
     span_end(c, sp);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    FameCounters fc;
+    memcpy(&fc, c->h_fame, sizeof fc);
+    const unsigned char* newc = c->h_fame + sizeof(FameCounters);
     const int call_idx = (int)c->fame_calls.size();
     c->fame_calls.push_back({max_c, R, c->divided});
     int cnt = 0;
@@ -1093,15 +1112,15 @@ int do_fame_partial(sw_ctx* c, int part, int nparts, int8_t* famous, uint8_t* de
     const int np = c->npad, n = c->n, R = c->R;
     const int max_c = first_undecided_round(c);
     CHK(fame_launch<NW>(c, max_c, part, nparts, nullptr));
-    std::vector<unsigned char> newc(R);
     std::vector<signed char> fam((size_t)R * np);
-    FameCounters fc{};
-    HIPCHK(c, hipMemcpyAsync(newc.data(), c->d_newc.p, R, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_fame, c->d_newc.p, sizeof(FameCounters) + (size_t)R, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(fam.data(), c->d_fam.p, fam.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&fc, c->d_fc, sizeof fc, hipMemcpyDeviceToHost, c->stream));
     // the kernel marks the rounds it completed in the device-side consensus flags; they become
     // official in sw_commit_fame, for every part alike
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    FameCounters fc;
+    memcpy(&fc, c->h_fame, sizeof fc);
+    const unsigned char* newc = c->h_fame + sizeof(FameCounters);
     for (int r = 0; r < R; ++r) {
         decided[r] = newc[r];
         const bool mine = r >= max_c && (r - max_c) % nparts == part;
@@ -1403,13 +1422,18 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         CHIP(hipEventCreateWithFlags(&c->ev_payload, hipEventDisableTiming));
         CHIP(hipEventCreateWithFlags(&c->ev_small, hipEventDisableTiming));
     }
-    CHIP(hipMalloc((void**)&c->d_state, 2 * sizeof(RState)));
-    CHIP(hipMemset(c->d_state, 0, 2 * sizeof(RState)));
-    CHIP(hipMalloc((void**)&c->d_fc, sizeof(FameCounters)));
-    CHIP(hipMemset(c->d_fc, 0, sizeof(FameCounters)));
+    {
+        static_assert(2 * sizeof(RState) + sizeof(int) <= 256, "readback block header");
+        c->rb_bytes = 256 + (size_t)c->npad * sizeof(int32_t);
+        CHIP(hipMalloc((void**)&c->d_rb, c->rb_bytes));
+        CHIP(hipMemset(c->d_rb, 0, c->rb_bytes));
+        CHIP(hipHostMalloc((void**)&c->h_rb, c->rb_bytes, hipHostMallocDefault));
+        c->d_state = reinterpret_cast<RState*>(c->d_rb);
+        c->d_flow_err = reinterpret_cast<int*>(c->d_rb + 2 * sizeof(RState));
+        c->d_front.p = reinterpret_cast<int32_t*>(c->d_rb + 256);
+    }
     CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
-    CHIP(hipMalloc((void**)&c->d_flow_err, sizeof(int)));
-    CHIP(hipMemset(c->d_flow_err, 0, sizeof(int)));
+
     const int np = c->npad;
     CCHK(dgrow(c, c->d_stake, np, 0));
     CHIP(hipMemcpy(c->d_stake.p, c->stake_h.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1425,7 +1449,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
     CCHK(dgrow(c, c->d_cand, (size_t)2 * np * 64, 0));
     CCHK(dgrow(c, c->d_gallop, 2 * np, 0));
-    CCHK(dgrow(c, c->d_front, np, 0));
     CCHK(fill_i32(c, c->d_front.p, np, -1));
     c->divided_cnt.assign(np, 0);
     CHIP(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
@@ -1488,11 +1511,11 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
-    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_front); dfree(c->d_small); dfree(c->d_Mb);
-    if (c->d_state) (void)hipFree(c->d_state);
-    if (c->d_fc) (void)hipFree(c->d_fc);
+    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
+    if (c->d_rb) (void)hipFree(c->d_rb);
+    if (c->h_rb) (void)hipHostFree(c->h_rb);
+    if (c->h_fame) (void)hipHostFree(c->h_fame);
     if (c->d_err) (void)hipFree(c->d_err);
-    if (c->d_flow_err) (void)hipFree(c->d_flow_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
     dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_acc_off); dfree(c->d_white);
     for (int g = 0; g < 3; ++g) {
