@@ -160,6 +160,21 @@ int sw_sync_diff(sw_ctx* ctx, int64_t head_event, const int32_t* known_height, i
                  int32_t* pos_end, int64_t* n_events);
 int sw_get_chain_events(sw_ctx* ctx, int member, int32_t p0, int32_t p1, int32_t* out);
 
+/*
+ * Ingest-side crypto in batches — what Node.is_valid_event spends its time in
+ * (swirld.py:99-103), stateless, one GPU thread per message; message i = msgs[msg_off[i] .. msg_off[i+1]).
+ * sw_crypto_verify_batch: ok[i] = 1 iff libsodium's crypto_sign_verify_detached(sig_i, msg_i, pk_i)
+ *   would return 0 (swirld.py:99-100 via pysodium): Ed25519 with libsodium 1.0.18's rejections
+ *   (non-canonical S, small-order R or key, non-canonical key).
+ * sw_crypto_hash_batch: out32[i] = BLAKE2b-256(msg_i) = crypto_generichash(msg_i), the event id
+ *   (swirld.py:95, 103).
+ * One signature costs a GPU thread ~1-2 ms of latency (a CPU core: ~60 us): batches of thousands
+ * (a bulk sync payload) are where the device wins; Node.sync uses it above a batch-size threshold.
+ */
+int sw_crypto_verify_batch(int device, int64_t K, const uint8_t* msgs, const int64_t* msg_off,
+                           const uint8_t* sig64, const uint8_t* pk32, uint8_t* ok);
+int sw_crypto_hash_batch(int device, int64_t K, const uint8_t* msgs, const int64_t* msg_off, uint8_t* out32);
+
 /* Exact work counters of the calls so far: used by bench.py's roofline. */
 typedef struct sw_counters {
     int64_t events_divided;      /* events through divide_rounds                          */

@@ -59,6 +59,8 @@ SIGNATURES = {
     "sw_get_known_heights": (C.c_int, [_P, C.c_int64, _P]),
     "sw_sync_diff": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.POINTER(C.c_int64)]),
     "sw_get_chain_events": (C.c_int, [_P, C.c_int, C.c_int32, C.c_int32, _P]),
+    "sw_crypto_verify_batch": (C.c_int, [C.c_int, C.c_int64, _P, _P, _P, _P, _P]),
+    "sw_crypto_hash_batch": (C.c_int, [C.c_int, C.c_int64, _P, _P, _P]),
     "sw_num_ordered": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sw_get_transactions": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_counters": (C.c_int, [_P, C.POINTER(Counters)]),

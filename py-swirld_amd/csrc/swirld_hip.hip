@@ -17,6 +17,7 @@
 
 #include "../../include/swirld_hip.h"
 #include "kernels.hip.h"
+#include "crypto.hip.h"
 
 namespace {
 
@@ -2204,4 +2205,68 @@ int sw_synchronize(sw_ctx* c) {
     return SW_OK;
 }
 
+
+// ---- ingest-side crypto batches: stateless, one thread per message ------------
+}  // extern "C"
+
+namespace {
+__global__ void __launch_bounds__(64)
+k_verify_batch(const uint8_t* __restrict__ msgs, const long long* __restrict__ off, const uint8_t* __restrict__ sig,
+               const uint8_t* __restrict__ pk, int K, uint8_t* ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    ok[i] = swc::ed25519_verify(sig + (size_t)i * 64, msgs + off[i], (uint64_t)(off[i + 1] - off[i]), pk + (size_t)i * 32) ? 1 : 0;
+}
+__global__ void __launch_bounds__(64)
+k_blake2b_batch(const uint8_t* __restrict__ msgs, const long long* __restrict__ off, int K, uint8_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    swc::blake2b_256(msgs + off[i], (uint64_t)(off[i + 1] - off[i]), out + (size_t)i * 32);
+}
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+int crypto_batch(int device, int64_t K, const uint8_t* msgs, const int64_t* off, const uint8_t* sig, const uint8_t* pk, uint8_t* out, bool verify) {
+    if (K < 0 || (K > 0 && (!msgs || !off || !out || (verify && (!sig || !pk))))) return fail(nullptr, SW_EINVAL, "NULL batch arrays");
+    if (K == 0) return SW_OK;
+    if (K > 0x7fffffff) return fail(nullptr, SW_ERANGE, "batch too large");
+    for (int64_t i = 0; i < K; ++i) if (off[i + 1] < off[i] || off[i] < 0) return fail(nullptr, SW_EINVAL, "message offsets must be non-decreasing");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(nullptr, SW_ENODEV, "no such HIP device (there is no CPU fallback)");
+    HIPCHK(nullptr, hipSetDevice(device));
+    const size_t nbytes = (size_t)off[K];
+    const size_t out_per = verify ? 1 : 32;
+    DevTmp d_m, d_off, d_sig, d_pk, d_out;
+    HIPCHK(nullptr, d_m.alloc(nbytes));
+    HIPCHK(nullptr, d_off.alloc((size_t)(K + 1) * 8));
+    HIPCHK(nullptr, d_out.alloc((size_t)K * out_per));
+    HIPCHK(nullptr, hipMemcpy(d_m.p, msgs, nbytes, hipMemcpyHostToDevice));
+    HIPCHK(nullptr, hipMemcpy(d_off.p, off, (size_t)(K + 1) * 8, hipMemcpyHostToDevice));
+    const unsigned blocks = (unsigned)((K + 63) / 64);
+    if (verify) {
+        HIPCHK(nullptr, d_sig.alloc((size_t)K * 64));
+        HIPCHK(nullptr, d_pk.alloc((size_t)K * 32));
+        HIPCHK(nullptr, hipMemcpy(d_sig.p, sig, (size_t)K * 64, hipMemcpyHostToDevice));
+        HIPCHK(nullptr, hipMemcpy(d_pk.p, pk, (size_t)K * 32, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_verify_batch, dim3(blocks), dim3(64), 0, nullptr, (const uint8_t*)d_m.p, (const long long*)d_off.p,
+                           (const uint8_t*)d_sig.p, (const uint8_t*)d_pk.p, (int)K, (uint8_t*)d_out.p);
+    } else {
+        hipLaunchKernelGGL(k_blake2b_batch, dim3(blocks), dim3(64), 0, nullptr, (const uint8_t*)d_m.p, (const long long*)d_off.p, (int)K, (uint8_t*)d_out.p);
+    }
+    HIPCHK(nullptr, hipGetLastError());
+    HIPCHK(nullptr, hipMemcpy(out, d_out.p, (size_t)K * out_per, hipMemcpyDeviceToHost));
+    return SW_OK;
+}
+}  // namespace
+
+extern "C" {
+int sw_crypto_verify_batch(int device, int64_t K, const uint8_t* msgs, const int64_t* msg_off, const uint8_t* sig64,
+                           const uint8_t* pk32, uint8_t* ok) {
+    return crypto_batch(device, K, msgs, msg_off, sig64, pk32, ok, true);
+}
+int sw_crypto_hash_batch(int device, int64_t K, const uint8_t* msgs, const int64_t* msg_off, uint8_t* out32) {
+    return crypto_batch(device, K, msgs, msg_off, nullptr, nullptr, out32, false);
+}
 }  // extern "C"

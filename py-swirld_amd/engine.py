@@ -218,6 +218,44 @@ class Hashgraph:
         self._chk(self._L.sw_synchronize(self._h))
 
 
+def _pack_messages(msgs):
+    off = np.zeros(len(msgs) + 1, np.int64)
+    np.cumsum([len(m) for m in msgs], out=off[1:])
+    return np.frombuffer(b"".join(msgs), np.uint8) if off[-1] else np.zeros(1, np.uint8), off
+
+
+def verify_batch(msgs, sigs, pks, device=0):
+    """Batch Ed25519 verification on the GPU (sw_crypto_verify_batch): one bool per (message,
+    64-byte signature, 32-byte public key), equal to libsodium's crypto_sign_verify_detached
+    accepting it (swirld.py:99-100)."""
+    L = _lib.load()
+    K = len(msgs)
+    if not (len(sigs) == len(pks) == K):
+        raise ValueError("msgs, sigs and pks must have equal length")
+    if any(len(s) != 64 for s in sigs) or any(len(p) != 32 for p in pks):
+        raise ValueError("signatures are 64 bytes, public keys 32 bytes")
+    data, off = _pack_messages(msgs)
+    sg = np.frombuffer(b"".join(sigs), np.uint8) if K else np.zeros(1, np.uint8)
+    pk = np.frombuffer(b"".join(pks), np.uint8) if K else np.zeros(1, np.uint8)
+    ok = np.zeros(max(K, 1), np.uint8)
+    rc = L.sw_crypto_verify_batch(int(device), K, _p(data), _p(off), _p(sg), _p(pk), _p(ok))
+    if rc != 0:
+        raise SwirldHipError(rc, (L.sw_last_error(None) or b"").decode())
+    return ok[:K].astype(bool)
+
+
+def hash_batch(msgs, device=0):
+    """Batch BLAKE2b-256 on the GPU (sw_crypto_hash_batch): the event ids of swirld.py:95, 103."""
+    L = _lib.load()
+    K = len(msgs)
+    data, off = _pack_messages(msgs)
+    out = np.zeros((max(K, 1), 32), np.uint8)
+    rc = L.sw_crypto_hash_batch(int(device), K, _p(data), _p(off), _p(out))
+    if rc != 0:
+        raise SwirldHipError(rc, (L.sw_last_error(None) or b"").decode())
+    return [bytes(out[i]) for i in range(K)]
+
+
 def synth_hashgraph(n, N, seed, mode=0, p0=0.0, p1=0.0, with_sig=True):
     """Host-side synthetic gossip hashgraph (csrc/synth.cpp): returns
     (creator, self_parent, other_parent, t, sig) as numpy arrays."""

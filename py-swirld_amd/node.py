@@ -202,6 +202,10 @@ class Node:
     # iteration order of a Python set (and with it the order concurrent events are added in) — so the
     # default keeps the BFS, which makes whole simulations reproduce the reference event for event.
     device_sync_diff = False
+    # Batched is_valid_event crypto on the GPU (sw_crypto_verify_batch / sw_crypto_hash_batch, SURVEY.md
+    # §8f N3) for sync payloads of at least this many events; smaller payloads go through libsodium on
+    # the host (one signature costs a GPU thread ~1-2 ms of latency, a CPU core ~60 us).  None = never.
+    device_crypto_threshold = 512
 
     def __init__(self, kp, network, n_nodes, stake, device=0):
         self.pk, self.sk = kp
@@ -231,6 +235,7 @@ class Node:
         self._pending = []    # (creator, self_parent, other_parent, t, sig) not yet uploaded
         self._uploaded = 0
         self._divided = 0
+        self._device = device
         self._dev = Hashgraph(n_nodes, [stake[pk] for pk in self._members], coin_period=C, device=device)
         self._round_cache = np.zeros(0, np.int32)
         self._wit_cache = None
@@ -284,10 +289,31 @@ class Node:
             return True
         return self._chain_head.get(ev.c) == (ev.p[0] if ev.p else None)
 
-    def is_valid_event(self, h, ev):
-        """Signature, hash and parent checks (swirld.py:97-108)."""
-        return (self._signature_ok(ev) and crypto.generichash(dumps(ev)) == h and self._parents_ok(ev)
-                and self._not_a_fork(h, ev))
+    def is_valid_event(self, h, ev, _crypto=None):
+        """Signature, hash and parent checks (swirld.py:97-108).  `_crypto` = (signature ok, event id)
+        when both were precomputed by a device batch."""
+        if _crypto is None:
+            sig_ok, hid = self._signature_ok(ev), crypto.generichash(dumps(ev))
+        else:
+            sig_ok, hid = _crypto
+        return bool(sig_ok) and hid == h and self._parents_ok(ev) and self._not_a_fork(h, ev)
+
+    def _batch_crypto(self, eids, events):
+        """{event id -> (signature ok, BLAKE2b-256 of the pickled event)} for a whole sync payload, on
+        the GPU.  Malformed signatures / keys (wrong type or length) are simply invalid."""
+        from .engine import hash_batch, verify_batch
+        msgs, sigs, pks, whole, good = [], [], [], [], []
+        for eid in eids:
+            ev = events[eid]
+            wf = isinstance(ev.s, (bytes, bytearray)) and len(ev.s) == 64 and isinstance(ev.c, (bytes, bytearray)) and len(ev.c) == 32
+            good.append(wf)
+            msgs.append(dumps(ev[:-1]))
+            sigs.append(bytes(ev.s) if wf else b"\0" * 64)
+            pks.append(bytes(ev.c) if wf else b"\0" * 32)
+            whole.append(dumps(ev))
+        ok = verify_batch(msgs, sigs, pks, device=self._device)
+        ids = hash_batch(whole, device=self._device)
+        return {eid: (bool(ok[i]) and good[i], ids[i]) for i, eid in enumerate(eids)}
 
     def add_event(self, h, ev):
         """Store an event (swirld.py:114-120); it is uploaded with the next divide_rounds."""
@@ -318,8 +344,10 @@ class Node:
         remote_head, remote_hg = loads(reply)
         unknown = remote_hg.keys() - self.hg.keys()
         new = tuple(toposort(unknown, lambda u: remote_hg[u].p))
+        thr = self.device_crypto_threshold
+        pre = self._batch_crypto(new, remote_hg) if thr is not None and len(new) >= thr else {}
         for eid in new:
-            if self.is_valid_event(eid, remote_hg[eid]):
+            if self.is_valid_event(eid, remote_hg[eid], pre.get(eid)):
                 self.add_event(eid, remote_hg[eid])
         if self.is_valid_event(remote_head, remote_hg[remote_head]):
             h, ev = self.new_event(payload, (self.head, remote_head))
