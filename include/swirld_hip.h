@@ -225,6 +225,20 @@ int sw_rewind(sw_ctx* ctx);
  * allocated.  Lets bench.py time repeated end-to-end passes (ingest included) on one context. */
 int sw_reset(sw_ctx* ctx);
 
+/*
+ * Windowed can_see table (the reference keeps every row forever, swirld.py:69-72,
+ * README.md:66-68).  sw_set_window(ctx, 1, chunk_mb) — before the first append — puts the table
+ * under HIP virtual memory management: one reserved address range, physical chunks (chunk_mb MB, 0 =
+ * 64) mapped as events arrive.  After every sw_find_order the rows no later call can read are
+ * evicted (chunks unmapped and recycled): rows older than every member's latest event, than every
+ * member's first unordered event, and than the thresholds of the oldest round still in play.
+ * Afterwards: sw_get_can_see / the gossip getters on an evicted row, and an appended event whose
+ * parent row was evicted, fail with SW_ERANGE; everything else behaves as without a window.
+ * sw_get_window: first resident event, bytes of the table currently mapped, number of evictions.
+ */
+int sw_set_window(sw_ctx* ctx, int enable, int chunk_mb);
+int sw_get_window(sw_ctx* ctx, int64_t* first_resident_event, int64_t* resident_bytes, int64_t* evictions);
+
 /* Block until all work queued on the context's stream is complete. */
 int sw_synchronize(sw_ctx* ctx);
 

@@ -2319,7 +2319,7 @@ __global__ void __launch_bounds__(256)
 k_order_times(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, int n_acc,
               const int* __restrict__ fw_ev, const int* __restrict__ fw_off, const int* __restrict__ L,
               const int* __restrict__ cr, const int* __restrict__ seq, const double* __restrict__ t,
-              const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int npad,
+              const int* __restrict__ chain_start, const int* __restrict__ chain_ev, const int* __restrict__ ord_pos, int npad,
               double* ts, int* err) {
     __shared__ double s_t[4][MAXS];
     const int lane = lane_id();
@@ -2342,7 +2342,11 @@ k_order_times(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, in
                 sees = true;
                 const int m = cr[w];
                 const int cs = chain_start[m];
-                int lo_ = 0, hi = seq[w];  // first position p in [0, seq[w]] with L[chain_m[p]][c] >= x
+                // first position p in [ord_pos[m], seq[w]] with L[chain_m[p]][c] >= x: the ordered prefix of m's chain
+                // cannot see an unordered x (the ordered set is ancestor-closed), so the search never touches its
+                // rows — which is what lets old can_see rows be evicted (windowed table)
+                int lo_ = ord_pos[m], hi = seq[w];
+                if (lo_ > hi) lo_ = hi;
                 while (lo_ < hi) {
                     const int mid = (lo_ + hi) >> 1;
                     if (L[(size_t)chain_ev[cs + mid] * npad + c] >= x) hi = mid; else lo_ = mid + 1;

@@ -31,8 +31,26 @@ struct DBuf {
 
 }  // namespace
 
+// can_see table under HIP virtual memory management (windowed mode, sw_set_window): ONE reserved address
+// range for the whole table, physical chunks mapped as events arrive and recycled from below the
+// eviction horizon — every kernel keeps the same base pointer and the same row arithmetic.
+struct VmTable {
+    bool active = false;
+    char* base = nullptr;
+    size_t va_bytes = 0, chunk = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handle;  // per chunk slot of the address range
+    std::vector<char> mapped;
+    std::vector<hipMemGenericAllocationHandle_t> pool;    // physical chunks unmapped by evictions, ready for reuse
+    size_t hi = 0;        // chunk slots [lo, hi) are mapped
+    size_t lo = 0;
+    int64_t evictions = 0;
+};
+
 struct sw_ctx {
     int n = 0, nw = 0, npad = 0, coin_period = 6, device = 0;
+    VmTable vm;
+    int64_t first_resident = 0;   // can_see rows below this event index have been evicted (windowed mode)
+    DBuf<int32_t> d_ordpos;       // per member: chain positions already ordered (find_order's search bound)
     bool unit_stake = true;
     uint32_t tot = 0;
     std::vector<uint32_t> stake_h;
@@ -232,6 +250,69 @@ int fill_i32(sw_ctx* c, int32_t* p, size_t n, int v) {
     return SW_OK;
 }
 
+// ---- windowed can_see table (VmTable) ----------------------------------------------------------
+int vm_map_slot(sw_ctx* c, size_t slot) {
+    VmTable& v = c->vm;
+    if (v.mapped[slot]) return SW_OK;
+    hipMemGenericAllocationHandle_t h;
+    if (!v.pool.empty()) { h = v.pool.back(); v.pool.pop_back(); }
+    else {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = c->device;
+        hipError_t e = hipMemCreate(&h, v.chunk, &prop, 0);
+        if (e != hipSuccess) return fail(c, SW_ENOMEM, "hipMemCreate(%zu bytes) failed: %s", v.chunk, hipGetErrorString(e));
+    }
+    hipError_t e = hipMemMap(v.base + slot * v.chunk, v.chunk, 0, h, 0);
+    if (e != hipSuccess) { v.pool.push_back(h); return fail(c, SW_EIO, "hipMemMap failed: %s", hipGetErrorString(e)); }
+    hipMemAccessDesc acc{};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = c->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    HIPCHK(c, hipMemSetAccess(v.base + slot * v.chunk, v.chunk, &acc, 1));
+    v.handle[slot] = h;
+    v.mapped[slot] = 1;
+    return SW_OK;
+}
+
+// make the table resident up to `bytes` (from the first resident chunk)
+int vm_ensure(sw_ctx* c, size_t bytes) {
+    VmTable& v = c->vm;
+    if (bytes > v.va_bytes) return fail(c, SW_ERANGE, "the windowed can_see table is limited to %zu GB of address space", v.va_bytes >> 30);
+    const size_t need_hi = (bytes + v.chunk - 1) / v.chunk;
+    for (size_t s_ = std::max(v.hi, v.lo); s_ < need_hi; ++s_) CHK(vm_map_slot(c, s_));
+    v.hi = std::max(v.hi, need_hi);
+    return SW_OK;
+}
+
+// unmap every chunk entirely below `bytes`; the physical chunks go to the pool
+int vm_evict_below(sw_ctx* c, size_t bytes) {
+    VmTable& v = c->vm;
+    const size_t new_lo = std::min(bytes / v.chunk, v.hi);
+    if (new_lo <= v.lo) return SW_OK;
+    HIPCHK(c, hipDeviceSynchronize());  // nothing in flight may still read those rows
+    for (size_t s_ = v.lo; s_ < new_lo; ++s_) {
+        if (!v.mapped[s_]) continue;
+        HIPCHK(c, hipMemUnmap(v.base + s_ * v.chunk, v.chunk));
+        v.pool.push_back(v.handle[s_]);
+        v.mapped[s_] = 0;
+    }
+    v.lo = new_lo;
+    v.evictions++;
+    return SW_OK;
+}
+
+void vm_destroy(sw_ctx* c) {
+    VmTable& v = c->vm;
+    if (!v.active) return;
+    for (size_t s_ = 0; s_ < v.mapped.size(); ++s_)
+        if (v.mapped[s_]) { (void)hipMemUnmap(v.base + s_ * v.chunk, v.chunk); (void)hipMemRelease(v.handle[s_]); }
+    for (auto h : v.pool) (void)hipMemRelease(h);
+    if (v.base) (void)hipMemAddressFree(v.base, v.va_bytes);
+    v = VmTable{};
+}
+
 int ensure_events(sw_ctx* c, int64_t need) {
     if (need <= c->cap) return SW_OK;
     int64_t nc = c->cap ? c->cap : 0;
@@ -248,7 +329,7 @@ int ensure_events(sw_ctx* c, int64_t need) {
     CHK(dgrow(c, c->d_t, nc, keep));
     CHK(dgrow(c, c->d_sig, (size_t)nc * 64, keep * 64));
     CHK(dgrow(c, c->d_S, (size_t)nc * c->nw, keep * c->nw));
-    CHK(dgrow(c, c->d_L, (size_t)nc * c->npad, keep * c->npad));
+    if (!c->vm.active) CHK(dgrow(c, c->d_L, (size_t)nc * c->npad, keep * c->npad));  // (windowed table: chunks are mapped per append)
     c->cap = nc;
     return SW_OK;
 }
@@ -1150,6 +1231,37 @@ int get_round_rows(sw_ctx* c, const T* src, int r0, int r1, T* out, T absent) {
 }
 
 
+// Windowed mode: evict every can_see row no later call can read.  Rows still needed: every member's
+// latest event (the self-parent row of its next event; recent other-parents), every member's first
+// not-yet-ordered event and what follows it (find_order's chain searches start at the ordered
+// prefix), and everything from the thresholds lo[r][.] of the oldest round still in play — the first
+// round not in `consensus` or the oldest front round of a member, whichever is older (band rows,
+// witness rows, voter masks, famous witnesses of rounds yet to be ordered).  A silent member pins
+// the horizon at its last event; the reference keeps every row forever (swirld.py:69-72).
+int window_evict(sw_ctx* c) {
+    if (!c->vm.active || c->divided != c->N || c->N == 0) return SW_OK;
+    const int n = c->n, np = c->npad;
+    int64_t horizon = c->N;
+    int fmin = 0x7fffffff;
+    CHK(ensure_pool_h(c));
+    for (int m = 0; m < n; ++m) {
+        if (c->head[m] >= 0) horizon = std::min<int64_t>(horizon, c->head[m]);
+        if (c->ord_pos[m] < c->nev[m]) horizon = std::min<int64_t>(horizon, c->chain_ev_h[(size_t)c->chain_start_h[m] + c->ord_pos[m]]);
+        if (c->front[m] >= 0) fmin = std::min(fmin, c->front[m]);
+    }
+    const int rmin = std::min(first_undecided_round(c), fmin == 0x7fffffff ? 0 : fmin);
+    if (rmin < c->R) {
+        std::vector<int32_t> row(np);
+        HIPCHK(c, hipMemcpyAsync(row.data(), c->d_lo.p + (size_t)rmin * np, np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int m = 0; m < n; ++m) if (row[m] != SW_INF) horizon = std::min<int64_t>(horizon, row[m]);
+    } else horizon = 0;
+    const size_t rowbytes = (size_t)np * sizeof(int32_t);
+    CHK(vm_evict_below(c, (size_t)std::max<int64_t>(horizon, 0) * rowbytes));
+    c->first_resident = (int64_t)((c->vm.lo * c->vm.chunk + rowbytes - 1) / rowbytes);
+    return SW_OK;
+}
+
 template <int NW>
 int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, int64_t cap, int64_t* n_out) {
     const int np = c->npad, n = c->n;
@@ -1228,11 +1340,18 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         HIPCHK(c, hipMemcpyAsync(c->d_acc_ev.p, acc_ev.data(), n_acc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_acc_ri.p, acc_ri.data(), n_acc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        CHK(dgrow(c, c->d_ordpos, np, 0));
+        {
+            std::vector<int32_t> op_(np, 0);
+            std::copy(c->ord_pos.begin(), c->ord_pos.end(), op_.begin());
+            HIPCHK(c, hipMemcpyAsync(c->d_ordpos.p, op_.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         hipLaunchKernelGGL(k_order_times<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
                            (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
                            (const int*)c->d_fw_off.p, (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_seq.p,
-                           (const double*)c->d_t.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, np,
-                           c->d_ts.p, c->d_err);
+                           (const double*)c->d_t.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
+                           (const int*)c->d_ordpos.p, np, c->d_ts.p, c->d_err);
         c->ctr.kernel_launches++;
         // device sort of every round's segment by (ts, first 8 whitened key bytes)
         CHK(dgrow(c, c->d_white, (size_t)nr * 64, 0));
@@ -1307,6 +1426,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     }
     lap("sort");
     c->ord_pos.swap(ord);
+    CHK(window_evict(c));
     if (n_out) *n_out = produced;
     if (produced > cap) return fail(c, SW_ERANGE, "find_order: out_events capacity %lld < %lld", (long long)cap, (long long)produced);
     return SW_OK;
@@ -1505,6 +1625,8 @@ int sw_destroy(sw_ctx* c) {
                 "round loop %.1f, front rows %.1f, aux launches %.1f, final syncs %.1f\n", (long long)c->stage_calls,
                 c->stage_us[0] * k, c->stage_us[1] * k, c->stage_us[2] * k, c->stage_us[3] * k, c->stage_us[4] * k, c->stage_us[5] * k);
     }
+    if (c->vm.active) { vm_destroy(c); c->d_L.p = nullptr; c->d_L.cap = 0; }
+    dfree(c->d_ordpos);
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
     dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
@@ -1685,6 +1807,8 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         if (m < 0 || m >= n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
         if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
         if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
+        if (s >= 0 && (s < c->first_resident || o < c->first_resident))
+            return fail(c, SW_ERANGE, "event %lld: the can_see row of a parent was evicted (windowed mode keeps rows from event %lld on)", (long long)e, (long long)c->first_resident);
         if (head_t[m] != s) {
             if (s >= 0 && (s < N0 ? c->cr[s] : creator[s - N0]) != m)
                 return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
@@ -1705,6 +1829,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     HIPCHK(c, hipSetDevice(c->device));
     // ---- 2. allocations (still nothing committed)
     CHK(ensure_events(c, N0 + K));
+    if (c->vm.active) CHK(vm_ensure(c, (size_t)(N0 + K) * c->npad * sizeof(int32_t)));
     if (!bulk) return append_small(c, K, creator, self_parent, other_parent, t, sig64, seq, head_t, nev_t, first_t);
     const size_t b4 = (size_t)K * sizeof(int32_t);
     const bool stage = bulk && (t || sig64) && (size_t)K * 72 <= ((size_t)1 << 30);  // (beyond 1 GiB of payload: plain copies)
@@ -1882,6 +2007,61 @@ int sw_commit_fame(sw_ctx* c, const int8_t* famous, const uint8_t* decided, int 
     return SW_OK;
 }
 
+int sw_set_window(sw_ctx* c, int enable, int chunk_mb) {
+    if (!c) return SW_EINVAL;
+    if (c->N != 0) return fail(c, SW_EINVAL, "sw_set_window must be called before the first event is appended");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!enable) {
+        if (c->vm.active) {
+            HIPCHK(c, hipDeviceSynchronize());
+            vm_destroy(c);
+            c->d_L.p = nullptr; c->d_L.cap = 0;
+            if (c->cap) CHK(dgrow(c, c->d_L, (size_t)c->cap * c->npad, 0));
+        }
+        return SW_OK;
+    }
+    if (c->vm.active) return SW_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    dfree(c->d_L);
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    size_t gran = 0;
+    HIPCHK(c, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (gran == 0) gran = 4096;
+    if (chunk_mb <= 0) chunk_mb = 64;
+    if (const char* e_ = getenv("SW_VM_CHUNK_MB")) chunk_mb = std::max(1, atoi(e_));
+    VmTable& v = c->vm;
+    v.chunk = (((size_t)chunk_mb << 20) + gran - 1) / gran * gran;
+    const size_t rowbytes = (size_t)c->npad * sizeof(int32_t);
+    size_t va = std::min<size_t>((size_t)0x7ffffff0ull * rowbytes, (size_t)4 << 40);  // up to 4 TB of address space
+    va = (va + v.chunk - 1) / v.chunk * v.chunk;
+    void* base = nullptr;
+    hipError_t e = hipMemAddressReserve(&base, va, 0, nullptr, 0);
+    if (e != hipSuccess) { v = VmTable{}; return fail(c, SW_ENOMEM, "hipMemAddressReserve(%zu GB) failed: %s", va >> 30, hipGetErrorString(e)); }
+    v.base = (char*)base;
+    v.va_bytes = va;
+    v.handle.assign(va / v.chunk, hipMemGenericAllocationHandle_t{});
+    v.mapped.assign(va / v.chunk, 0);
+    v.active = true;
+    c->d_L.p = (int32_t*)base;
+    c->d_L.cap = va / sizeof(int32_t);
+    c->first_resident = 0;
+    return SW_OK;
+}
+
+int sw_get_window(sw_ctx* c, int64_t* first_resident_event, int64_t* resident_bytes, int64_t* evictions) {
+    if (!c) return SW_EINVAL;
+    if (first_resident_event) *first_resident_event = c->first_resident;
+    if (resident_bytes) {
+        if (c->vm.active) { size_t cnt = 0; for (char m_ : c->vm.mapped) cnt += m_ != 0; *resident_bytes = (int64_t)(cnt * c->vm.chunk); }
+        else *resident_bytes = (int64_t)(c->d_L.cap * sizeof(int32_t));
+    }
+    if (evictions) *evictions = c->vm.evictions;
+    return SW_OK;
+}
+
 int sw_rewind(sw_ctx* c) {
     if (!c) return SW_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1904,6 +2084,12 @@ int sw_rewind(sw_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::fill(c->front.begin(), c->front.end(), -1);
     std::fill(c->divided_cnt.begin(), c->divided_cnt.end(), 0);
+    if (c->vm.active && c->vm.lo > 0) {  // every row is recomputed from event 0: map the evicted chunks again
+        const size_t old_lo = c->vm.lo;
+        c->vm.lo = 0;
+        for (size_t s_ = 0; s_ < old_lo; ++s_) CHK(vm_map_slot(c, s_));
+        c->first_resident = 0;
+    }
     std::fill(c->divided_head.begin(), c->divided_head.end(), -1);
     std::fill(c->lo0_h.begin(), c->lo0_h.end(), SW_INF);
     std::fill(c->cons_h.begin(), c->cons_h.end(), 0);
@@ -1980,6 +2166,7 @@ int sw_get_can_see(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
     if (!c || !out) return SW_EINVAL;
     if (first < 0 || K < 0 || first + K > c->divided) return fail(c, SW_ERANGE, "range outside the divided events");
     if (!K) return SW_OK;
+    if (first < c->first_resident) return fail(c, SW_ERANGE, "can_see rows below event %lld were evicted (windowed mode)", (long long)c->first_resident);
     HIPCHK(c, hipSetDevice(c->device));
     const int np = c->npad, n = c->n;
     const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (np * 4));
@@ -2108,7 +2295,7 @@ int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
 
 int sw_get_known_heights(sw_ctx* c, int64_t head_event, int32_t* out) {
     if (!c || !out) return SW_EINVAL;
-    if (head_event < 0 || head_event >= c->divided) return fail(c, SW_ERANGE, "head %lld is not a divided event", (long long)head_event);
+    if (head_event < c->first_resident || head_event >= c->divided) return fail(c, SW_ERANGE, "head %lld is not a divided, resident event", (long long)head_event);
     HIPCHK(c, hipSetDevice(c->device));
     CHK(ensure_dag_h(c));  // heights on the device
     const int np = c->npad;
@@ -2124,7 +2311,7 @@ int sw_get_known_heights(sw_ctx* c, int64_t head_event, int32_t* out) {
 
 int sw_sync_diff(sw_ctx* c, int64_t head_event, const int32_t* known_height, int32_t* pos_first, int32_t* pos_end, int64_t* n_events) {
     if (!c || !known_height || !pos_first || !pos_end) return SW_EINVAL;
-    if (head_event < 0 || head_event >= c->divided) return fail(c, SW_ERANGE, "head %lld is not a divided event", (long long)head_event);
+    if (head_event < c->first_resident || head_event >= c->divided) return fail(c, SW_ERANGE, "head %lld is not a divided, resident event", (long long)head_event);
     HIPCHK(c, hipSetDevice(c->device));
     CHK(ensure_dag_h(c));
     const int np = c->npad, n = c->n;

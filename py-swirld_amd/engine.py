@@ -206,6 +206,17 @@ class Hashgraph:
         self._chk(self._L.sw_debug_clocks(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
 
+    def set_window(self, enable=True, chunk_mb=0):
+        """Windowed can_see table (before the first append): rows no later call can read are evicted
+        after every find_order (HIP virtual memory management, include/swirld_hip.h)."""
+        self._chk(self._L.sw_set_window(self._h, 1 if enable else 0, int(chunk_mb)))
+
+    def window(self):
+        """(first resident event, bytes of the can_see table currently mapped, evictions so far)."""
+        a, b, e = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._L.sw_get_window(self._h, C.byref(a), C.byref(b), C.byref(e)))
+        return int(a.value), int(b.value), int(e.value)
+
     def rewind(self):
         """Forget all voting state; the ingested events stay resident (bench utility)."""
         self._chk(self._L.sw_rewind(self._h))

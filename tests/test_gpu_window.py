@@ -1,0 +1,68 @@
+"""GPU (-m gpu): the windowed can_see table (sw_set_window).  A long incremental run —
+append, divide_rounds, decide_fame, find_order per call — with row eviction switched on must give
+exactly the reference algorithm's rounds, fame, consensus and total order while the resident part
+of the table stays a small fraction of what the reference would keep; evicted rows are refused
+cleanly; a rewind maps everything again."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,N,chunk,mode,p0,p1", [(64, 400_000, 20_000, 0, 0, 0), (24, 150_000, 3_000, 2, 0.25, 0.2), (256, 300_000, 25_000, 0, 0, 0)])
+def test_windowed_run_matches_oracle(pkg, n, N, chunk, mode, p0, p1):
+    from oracle.oracle import Oracle
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 701, mode, p0, p1)
+    o, h = Oracle(n), pkg.Hashgraph(n)
+    h.set_window(True, chunk_mb=2)
+    peak = 0
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        for d in (o, h):
+            d.append_events(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+            d.divide_rounds(a, b - a)
+        nco, nch = list(o.decide_fame()), list(h.decide_fame())
+        assert nco == nch
+        assert list(h.find_order(nch)) == list(o.find_order(nco))
+        first, resident, _ = h.window()
+        peak = max(peak, resident)
+    assert np.array_equal(h.rounds(), o.round)
+    wit = h.witnesses()
+    assert np.array_equal(wit, o.witnesses())
+    m = wit >= 0
+    assert np.array_equal(h.famous()[m], o.famous_by_event[wit[m]])
+    assert np.array_equal(h.transactions(), o.transactions)
+    first, resident, evictions = h.window()
+    full = N * ((n + 63) // 64 * 64) * 4
+    assert evictions > 3 and first > N // 2, "most of the table must have been evicted"
+    assert peak < full // 2, "the resident part stays well below the full table (%d of %d bytes)" % (peak, full)
+    # resident rows are exact, evicted rows are refused
+    assert np.array_equal(h.can_see(first, N - first), o.can_see[first:])
+    with pytest.raises(pkg.SwirldHipError) as ei:
+        h.can_see(0, 1)
+    assert ei.value.code == -34
+    with pytest.raises(pkg.SwirldHipError) as ei:      # an event on top of an evicted parent
+        h.append_events([int(cr[N - 1])], [N - 1], [0 if cr[0] != cr[N - 1] else 1])
+    assert ei.value.code == -34 and h.num_events == N
+    # a rewind recomputes everything from event 0: the evicted chunks are mapped again
+    h.rewind()
+    h.divide_rounds(0, N)
+    h.decide_fame()
+    assert np.array_equal(h.rounds(), o.round)
+    assert np.array_equal(h.can_see(0, 2000), o.can_see[:2000])
+    h.close()
+
+
+def test_window_must_be_set_before_the_first_append(pkg):
+    h = pkg.Hashgraph(4)
+    h.append_events([0, 1, 2, 3], [-1] * 4, [-1] * 4)
+    with pytest.raises(pkg.SwirldHipError):
+        h.set_window(True)
+    h.close()
+    h = pkg.Hashgraph(4)
+    h.set_window(True)
+    h.set_window(False)            # back to the plain table
+    h.append_events([0, 1, 2, 3], [-1] * 4, [-1] * 4)
+    h.divide_rounds(0, 4)
+    assert list(h.rounds()) == [0, 0, 0, 0]
+    h.close()
