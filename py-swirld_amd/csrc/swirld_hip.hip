@@ -2084,11 +2084,23 @@ int sw_rewind(sw_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::fill(c->front.begin(), c->front.end(), -1);
     std::fill(c->divided_cnt.begin(), c->divided_cnt.end(), 0);
-    if (c->vm.active && c->vm.lo > 0) {  // every row is recomputed from event 0: map the evicted chunks again
-        const size_t old_lo = c->vm.lo;
-        c->vm.lo = 0;
-        for (size_t s_ = 0; s_ < old_lo; ++s_) CHK(vm_map_slot(c, s_));
+    if (c->vm.active && c->vm.lo > 0) {
+        // every row is recomputed from event 0.  The evicted part is NOT mapped again at its old addresses
+        // (an address range that was unmapped is never reused: no reliance on translation caches being
+        // flushed); the whole table moves to a fresh reservation, physical chunks recycled through the pool.
+        HIPCHK(c, hipDeviceSynchronize());
+        VmTable& v = c->vm;
+        for (size_t s_ = 0; s_ < v.mapped.size(); ++s_)
+            if (v.mapped[s_]) { HIPCHK(c, hipMemUnmap(v.base + s_ * v.chunk, v.chunk)); v.pool.push_back(v.handle[s_]); v.mapped[s_] = 0; }
+        HIPCHK(c, hipMemAddressFree(v.base, v.va_bytes));
+        void* base = nullptr;
+        hipError_t e = hipMemAddressReserve(&base, v.va_bytes, 0, nullptr, 0);
+        if (e != hipSuccess) { c->poisoned = true; return fail(c, SW_ENOMEM, "hipMemAddressReserve failed on rewind: %s", hipGetErrorString(e)); }
+        v.base = (char*)base;
+        v.lo = 0; v.hi = 0;
+        c->d_L.p = (int32_t*)base;
         c->first_resident = 0;
+        CHK(vm_ensure(c, (size_t)c->N * c->npad * sizeof(int32_t)));
     }
     std::fill(c->divided_head.begin(), c->divided_head.end(), -1);
     std::fill(c->lo0_h.begin(), c->lo0_h.end(), SW_INF);
