@@ -212,6 +212,16 @@ int fail(sw_ctx* c, int code, const char* fmt, ...) {
         if (rc_ != SW_OK) return rc_; \
     } while (0)
 
+// debugging aid (SW_POISON=<byte>): fresh device memory is filled with that byte, so that a read of
+// memory no kernel has written shows up in any test instead of depending on what the heap held before
+int poison_byte() {
+    static const int v = [] { const char* e = getenv("SW_POISON"); return e && *e ? (int)(strtol(e, nullptr, 0) & 0xff) : -1; }();
+    return v;
+}
+void poison(void* p, size_t bytes) {
+    if (poison_byte() >= 0 && p && bytes) { (void)hipMemset(p, poison_byte(), bytes); (void)hipDeviceSynchronize(); }
+}
+
 // grow a device buffer to >= need elements, preserving the first `keep` elements
 template <class T>
 int dgrow(sw_ctx* c, DBuf<T>& b, size_t need, size_t keep) {
@@ -222,6 +232,7 @@ int dgrow(sw_ctx* c, DBuf<T>& b, size_t need, size_t keep) {
     T* q = nullptr;
     hipError_t e = hipMalloc((void**)&q, nc * sizeof(T));
     if (e != hipSuccess) return fail(c, SW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", nc * sizeof(T), hipGetErrorString(e));
+    poison(q, nc * sizeof(T));
     if (b.p) {
         // the old buffer may still be in use on any of the context's streams (calls return without a
         // host synchronisation): drain the device before it is copied and freed — reallocation is rare
@@ -271,8 +282,24 @@ int vm_map_slot(sw_ctx* c, size_t slot) {
     acc.location.id = c->device;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     HIPCHK(c, hipMemSetAccess(v.base + slot * v.chunk, v.chunk, &acc, 1));
+    poison(v.base + slot * v.chunk, v.chunk);
     v.handle[slot] = h;
     v.mapped[slot] = 1;
+    return SW_OK;
+}
+
+// After hipMemUnmap the GPU's translation caches may still hold the old address -> chunk translation
+// (measured: profiles/microbench/vmm_remap.hip; the unmap of the virtual-memory-management path does
+// not invalidate them, the driver's map / unmap of an ordinary allocation does).  A recycled chunk
+// or a re-used address would then be written through the stale entry.  Every batch of unmaps is
+// therefore followed by one ordinary 4 MB allocation + free (above the runtime's sub-allocator
+// threshold, so it reaches the driver).  SW_VM_FLUSH=0 switches this off (experiments only).
+int vm_flush_translations(sw_ctx* c) {
+    static const bool on = [] { const char* e = getenv("SW_VM_FLUSH"); return !(e && atoi(e) == 0); }();
+    if (!on) return SW_OK;
+    void* t = nullptr;
+    HIPCHK(c, hipMalloc(&t, (size_t)4 << 20));
+    HIPCHK(c, hipFree(t));
     return SW_OK;
 }
 
@@ -300,7 +327,7 @@ int vm_evict_below(sw_ctx* c, size_t bytes) {
     }
     v.lo = new_lo;
     v.evictions++;
-    return SW_OK;
+    return vm_flush_translations(c);
 }
 
 void vm_destroy(sw_ctx* c) {
@@ -311,6 +338,7 @@ void vm_destroy(sw_ctx* c) {
     for (auto h : v.pool) (void)hipMemRelease(h);
     if (v.base) (void)hipMemAddressFree(v.base, v.va_bytes);
     v = VmTable{};
+    (void)vm_flush_translations(c);
 }
 
 int ensure_events(sw_ctx* c, int64_t need) {
@@ -818,6 +846,7 @@ int launch_voter_masks(sw_ctx* c, int r0, int R, hipStream_t strm) {
         u64* q = nullptr;
         hipError_t e = hipMalloc((void**)&q, (size_t)nr * np * NW * sizeof(u64));
         if (e != hipSuccess) return fail(c, SW_ENOMEM, "hipMalloc(Sw) failed: %s", hipGetErrorString(e));
+        poison(q, (size_t)nr * np * NW * sizeof(u64));
         HIPCHK(c, hipStreamSynchronize(c->stream_aux));
         if (c->Sw_rows && c->d_Sw.p)
             HIPCHK(c, hipMemcpy(q, c->d_Sw.p, (size_t)c->Sw_rows * np * NW * sizeof(u64), hipMemcpyDeviceToDevice));
@@ -1517,7 +1546,9 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         c->ring_H = H;
     }
     c->BATCH = (c->BATCH + 1) & ~1;  // even: the loop state is double-buffered by iteration parity
-    c->K = (c->K + 3) & ~3;  // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway)
+    // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway); a member's row of the candidate
+    // table has 64 slots and slot 0 is the window header, so at most 60 candidates after rounding
+    c->K = std::min((c->K + 3) & ~3, 60);
     auto bail = [&](int rc) { g_create_error = c->err; sw_destroy(c); return rc; };
 #define CCHK(expr) do { int rc_ = (expr); if (rc_ != SW_OK) return bail(rc_); } while (0)
 #define CHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, SW_EIO, "%s: %s", #expr, hipGetErrorString(e_)); return bail(SW_EIO); } } while (0)
@@ -2085,17 +2116,17 @@ int sw_rewind(sw_ctx* c) {
     std::fill(c->front.begin(), c->front.end(), -1);
     std::fill(c->divided_cnt.begin(), c->divided_cnt.end(), 0);
     if (c->vm.active && c->vm.lo > 0) {
-        // every row is recomputed from event 0.  The evicted part is NOT mapped again at its old addresses
-        // (an address range that was unmapped is never reused: no reliance on translation caches being
-        // flushed); the whole table moves to a fresh reservation, physical chunks recycled through the pool.
+        // every row is recomputed from event 0: the whole table moves to a fresh reservation (made before
+        // the old one is given back, so the addresses differ), physical chunks recycled through the pool
         HIPCHK(c, hipDeviceSynchronize());
         VmTable& v = c->vm;
-        for (size_t s_ = 0; s_ < v.mapped.size(); ++s_)
-            if (v.mapped[s_]) { HIPCHK(c, hipMemUnmap(v.base + s_ * v.chunk, v.chunk)); v.pool.push_back(v.handle[s_]); v.mapped[s_] = 0; }
-        HIPCHK(c, hipMemAddressFree(v.base, v.va_bytes));
         void* base = nullptr;
         hipError_t e = hipMemAddressReserve(&base, v.va_bytes, 0, nullptr, 0);
         if (e != hipSuccess) { c->poisoned = true; return fail(c, SW_ENOMEM, "hipMemAddressReserve failed on rewind: %s", hipGetErrorString(e)); }
+        for (size_t s_ = 0; s_ < v.mapped.size(); ++s_)
+            if (v.mapped[s_]) { HIPCHK(c, hipMemUnmap(v.base + s_ * v.chunk, v.chunk)); v.pool.push_back(v.handle[s_]); v.mapped[s_] = 0; }
+        HIPCHK(c, hipMemAddressFree(v.base, v.va_bytes));
+        CHK(vm_flush_translations(c));
         v.base = (char*)base;
         v.lo = 0; v.hi = 0;
         c->d_L.p = (int32_t*)base;

@@ -48,7 +48,20 @@ def test_windowed_run_matches_oracle(pkg, n, N, chunk, mode, p0, p1):
     h.rewind()
     h.divide_rounds(0, N)
     h.decide_fame()
-    assert np.array_equal(h.rounds(), o.round)
+    hr = h.rounds()
+    if not np.array_equal(hr, o.round):   # say where the two part: the first wrong round and the wrong can_see rows
+        bad = int(np.flatnonzero(hr != o.round)[0])
+        hc = h.can_see(0, N)
+        wrong = (hc != o.can_see).any(axis=1)
+        rows = np.flatnonzero(wrong)
+        edges = np.flatnonzero(np.diff(np.concatenate(([0], wrong.astype(np.int8), [0]))))
+        spans = list(zip(edges[0::2].tolist(), edges[1::2].tolist()))[:12]
+        r0 = int(rows[0]) if len(rows) else 0
+        same = np.flatnonzero((o.can_see == hc[r0]).all(axis=1))[:4] if len(rows) else []
+        const = int(sum(len(np.unique(hc[r])) == 1 for r in rows[:: max(1, len(rows) // 256)]))
+        pytest.fail("after the rewind: first wrong round at event %d (%d, expected %d; %d wrong in all); can_see rows wrong: %d in spans %s; "
+                    "row %d holds %s, expected %s; oracle rows equal to it: %s; constant rows in a sample of 256: %d"
+                    % (bad, hr[bad], o.round[bad], int((hr != o.round).sum()), len(rows), spans, r0, hc[r0][:8], o.can_see[r0][:8], same, const))
     assert np.array_equal(h.can_see(0, 2000), o.can_see[:2000])
     h.close()
 
