@@ -35,7 +35,7 @@ extern "C" {
 #define SW_EINVAL     (-22)
 #define SW_ERANGE     (-34)  /* index / round range outside the stored hashgraph        */
 #define SW_EOVERFLOW  (-75)  /* total stake too large for the 32-bit tally              */
-#define SW_ENOTSUP    (-95)  /* input outside the supported domain (e.g. forked DAG)    */
+#define SW_ENOTSUP    (-95)  /* outside the supported domain (forks refused, exact path) */
 
 #define SW_MAX_MEMBERS 1024
 
@@ -68,10 +68,11 @@ int sw_reserve(sw_ctx* ctx, int64_t n_events);
  * Validation mirrors is_valid_event's structural half (swirld.py:104-108): parents
  * must exist, self-parent must be by the same creator, other-parent by another.
  * A fork (an event whose self-parent is not its creator's latest event, or a second
- * root of one member) is refused with SW_ENOTSUP and NOTHING of the call is stored:
- * the round-synchronous path needs one self-parent chain per member (the reference
- * has no fork detection and leaves fork behaviour unspecified, README.md:84; the
- * drop-in Node drops forked events in is_valid_event so that it keeps running).
+ * root of one member) is stored, as the reference stores it (no fork detection,
+ * README.md:84), and moves the context to the EXACT path (sw_set_forks below): from
+ * then on every call runs the reference's own statements on the device, one wavefront,
+ * results identical to the reference's on forked input — and far slower than the
+ * round-synchronous path, which needs one self-parent chain per member.
  */
 int sw_append_events(sw_ctx* ctx, int64_t K, const int32_t* creator, const int32_t* self_parent,
                      const int32_t* other_parent, const double* t, const uint8_t* sig64);
@@ -238,6 +239,24 @@ int sw_reset(sw_ctx* ctx);
  */
 int sw_set_window(sw_ctx* ctx, int enable, int chunk_mb);
 int sw_get_window(sw_ctx* ctx, int64_t* first_resident_event, int64_t* resident_bytes, int64_t* evictions);
+
+/*
+ * Forked hashgraphs (swirld.py:170-184 height-based maxi, :221-222 witness overwrite, README.md:84).
+ * sw_set_forks(ctx, 1) [default]: a forked event is accepted and the context switches, once and for
+ * good (until sw_reset), to the exact path — csrc/exact.hip.h, the reference's divide_rounds /
+ * decide_fame / find_order statement by statement on the device-resident state, the fast path's
+ * state handed over as it is.  sw_set_forks(ctx, 0): forked events are refused with SW_ENOTSUP and
+ * nothing of the call is stored (what a Node that drops forked events wants).  Not available on the
+ * exact path (SW_ENOTSUP): sw_decide_fame_partial / sw_commit_fame, sw_get_vote, sw_get_sees_mask,
+ * sw_sync_diff, sw_get_chain_events, the windowed table.
+ * sw_get_exact: 1 once the context runs on the exact path.
+ * sw_get_witness_order: the members of witnesses[r] in dict insertion order (swirld.py:234, 240) —
+ * on the fast path the ascending event index of the table entries; with forks the position of a
+ * member's FIRST witness of the round (a fork sibling replaces the value, not the position).
+ */
+int sw_set_forks(sw_ctx* ctx, int accept);
+int sw_get_exact(sw_ctx* ctx, int* out);
+int sw_get_witness_order(sw_ctx* ctx, int r, int32_t* members, int* n_out);
 
 /* Block until all work queued on the context's stream is complete. */
 int sw_synchronize(sw_ctx* ctx);

@@ -18,6 +18,7 @@
 #include "../../include/swirld_hip.h"
 #include "kernels.hip.h"
 #include "crypto.hip.h"
+#include "exact.hip.h"
 
 namespace {
 
@@ -51,6 +52,17 @@ struct sw_ctx {
     VmTable vm;
     int64_t first_resident = 0;   // can_see rows below this event index have been evicted (windowed mode)
     DBuf<int32_t> d_ordpos;       // per member: chain positions already ordered (find_order's search bound)
+    // exact path for forked hashgraphs (exact.hip.h): entered at the first forked event, left by sw_reset
+    bool exact = false;
+    int forks_mode = 1;           // 1: accept forks (exact path), 0: refuse them (SW_ENOTSUP, nothing stored)
+    DBuf<int32_t> x_worder, x_wcnt, x_newr, x_queue, x_fw, x_items_ev, x_rounds;
+    DBuf<signed char> x_fam_ev, x_votes;
+    DBuf<unsigned char> x_tbd, x_sm, x_done, x_visited, x_sflag, x_white;
+    DBuf<double> x_times, x_tsort, x_items_ts;
+    DBuf<long long> x_hdr;
+    int x_Rcap = 0;               // rows of x_worder / x_wcnt / x_done / x_newr
+    int64_t x_cap = 0;            // events of x_fam_ev / x_tbd / x_queue / x_visited / x_items_*
+    FameCounters x_fc_base{};     // fame counters of the fast path at the switch (the exact path counts from zero)
     bool unit_stake = true;
     uint32_t tot = 0;
     std::vector<uint32_t> stake_h;
@@ -1658,6 +1670,9 @@ int sw_destroy(sw_ctx* c) {
     }
     if (c->vm.active) { vm_destroy(c); c->d_L.p = nullptr; c->d_L.cap = 0; }
     dfree(c->d_ordpos);
+    dfree(c->x_worder); dfree(c->x_wcnt); dfree(c->x_newr); dfree(c->x_queue); dfree(c->x_fw); dfree(c->x_items_ev); dfree(c->x_rounds);
+    dfree(c->x_fam_ev); dfree(c->x_votes); dfree(c->x_tbd); dfree(c->x_sm); dfree(c->x_done); dfree(c->x_visited); dfree(c->x_sflag);
+    dfree(c->x_white); dfree(c->x_times); dfree(c->x_tsort); dfree(c->x_items_ts); dfree(c->x_hdr);
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
     dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
@@ -1714,6 +1729,251 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
         if (a1 > a0) th.emplace_back([=] { memcpy((char*)dst + a0, (const char*)src + a0, a1 - a0); });
     }
     for (auto& t : th) t.join();
+}
+
+// ---- exact path for forked hashgraphs (exact.hip.h) ----------------------------------------------
+// The context's own tables are the state (can_see table, round array, witness / fame / consensus
+// tables); what the reference keeps beyond the fast path's per-slot view is added here: the dict order
+// of every round's witnesses, fame per EVENT, tbd.  Every call is one launch of one wavefront.
+swx::State exact_state(sw_ctx* c) {
+    swx::State s{};
+    s.n = c->n; s.npad = c->npad; s.coin_period = c->coin_period; s.tot = c->tot; s.stake = c->d_stake.p;
+    s.cr = c->d_cr.p; s.sp = c->d_sp.p; s.op = c->d_op.p; s.ht = c->d_ht.p; s.t = c->d_t.p; s.sig = c->d_sig.p;
+    s.round = c->d_round.p; s.L = c->d_L.p; s.tbd = c->x_tbd.p; s.fam_ev = c->x_fam_ev.p;
+    s.Rcap = c->Rcap; s.wit = c->d_wit.p; s.worder = c->x_worder.p; s.wcnt = c->x_wcnt.p; s.cons = c->d_cons.p;
+    s.fam_slot = c->d_fam.p; s.hdr = c->x_hdr.p;
+    return s;
+}
+
+// per-event and per-round buffers of the exact path follow the context's capacities
+int exact_grow(sw_ctx* c) {
+    const size_t np = c->npad;
+    if (c->x_cap < c->cap) {
+        const size_t keep = (size_t)c->x_cap, nc = (size_t)c->cap;
+        CHK(dgrow(c, c->x_fam_ev, nc, keep));
+        CHK(dgrow(c, c->x_tbd, nc, keep));
+        CHK(dgrow(c, c->x_queue, nc + 1, 0));
+        CHK(dgrow(c, c->x_visited, nc + 1, 0));
+        CHK(dgrow(c, c->x_items_ev, nc + 1, 0));
+        CHK(dgrow(c, c->x_items_ts, nc + 1, 0));
+        HIPCHK(c, hipMemsetAsync(c->x_fam_ev.p + keep, 0xff, nc - keep, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->x_tbd.p + keep, 1, nc - keep, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->x_visited.p, 0, c->x_visited.cap, c->stream));  // all zero between calls
+        c->x_cap = c->cap;
+    }
+    if (c->x_Rcap < c->Rcap) {
+        const size_t keep = (size_t)c->x_Rcap, nc = (size_t)c->Rcap;
+        CHK(dgrow(c, c->x_worder, nc * np, keep * np));
+        CHK(dgrow(c, c->x_wcnt, nc, keep));
+        CHK(dgrow(c, c->x_done, nc, 0));
+        CHK(dgrow(c, c->x_newr, nc, 0));
+        HIPCHK(c, hipMemsetAsync(c->x_wcnt.p + keep, 0, (nc - keep) * sizeof(int32_t), c->stream));
+        c->x_Rcap = c->Rcap;
+    }
+    return SW_OK;
+}
+
+int exact_read_hdr(sw_ctx* c, long long* hdr) {
+    HIPCHK(c, hipMemcpyAsync(hdr, c->x_hdr.p, swx::H_WORDS * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SW_OK;
+}
+
+int exact_set_hdr(sw_ctx* c, int slot, long long v) {
+    HIPCHK(c, hipMemcpyAsync(c->x_hdr.p + slot, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SW_OK;
+}
+
+// The first forked event arrives: hand the fast path's state over (nothing of it is recomputed).
+int exact_enter(sw_ctx* c) {
+    if (c->vm.active) return fail(c, SW_ENOTSUP, "a forked event in windowed mode: the exact path needs every can_see row");
+    HIPCHK(c, hipDeviceSynchronize());
+    c->payload_pending = false; c->small_pending = false;
+    CHK(ensure_dag_h(c));  // host sp / op / height complete, heights on the device
+    CHK(ensure_rounds(c, std::max(c->max_height + 3, c->R + 1)));
+    const size_t np = c->npad;
+    CHK(dgrow(c, c->x_hdr, (size_t)swx::H_WORDS, 0));
+    CHK(dgrow(c, c->x_sm, np, 0)); CHK(dgrow(c, c->x_fw, np, 0)); CHK(dgrow(c, c->x_sflag, np, 0));
+    CHK(dgrow(c, c->x_times, np, 0)); CHK(dgrow(c, c->x_tsort, np, 0)); CHK(dgrow(c, c->x_white, 64, 0));
+    CHK(exact_grow(c));
+    long long hdr[swx::H_WORDS] = {0};
+    hdr[swx::H_R] = c->R;
+    HIPCHK(c, hipMemcpyAsync(c->x_hdr.p, hdr, sizeof hdr, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->x_wcnt.p, 0, (size_t)c->x_Rcap * sizeof(int32_t), c->stream));
+    c->x_fc_base = c->fc_seen;
+    const long long n_tx = (long long)c->transactions.size();
+    if (n_tx) HIPCHK(c, hipMemcpyAsync(c->x_items_ev.p, c->transactions.data(), (size_t)n_tx * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_exact_import, dim3(1), dim3(64), 0, c->stream, exact_state(c), (long long)c->N, (const int*)c->x_items_ev.p, n_tx);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->exact = true;
+    return SW_OK;
+}
+
+// Node.add_event for a context on the exact path (swirld.py:114-120) + the structural half of
+// is_valid_event (swirld.py:104-108: 0 or 2 parents, both known, self-parent by the creator,
+// other-parent by another member).  Nothing is stored before the whole batch is accepted.
+int append_exact(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t* self_parent, const int32_t* other_parent,
+                 const double* t, const uint8_t* sig64) {
+    const int64_t N0 = c->N;
+    const int n = c->n;
+    for (int64_t i = 0; i < K; ++i) {
+        const int64_t e = N0 + i;
+        const int32_t m = creator[i], s = self_parent[i], o = other_parent[i];
+        if (m < 0 || m >= n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
+        if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
+        if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
+        if (s >= 0) {
+            if ((s < N0 ? c->cr[s] : creator[s - N0]) != m) return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
+            if ((o < N0 ? c->cr[o] : creator[o - N0]) == m) return fail(c, SW_EINVAL, "event %lld: other-parent is by the same member", (long long)e);
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->exact) CHK(exact_enter(c));
+    CHK(ensure_events(c, N0 + K));
+    CHK(exact_grow(c));
+    std::vector<int32_t> hnew(K);
+    int hmax = c->max_height;
+    for (int64_t i = 0; i < K; ++i) {  // swirld.py:117-120
+        const int32_t s = self_parent[i], o = other_parent[i];
+        if (s < 0) { hnew[i] = 0; continue; }
+        const int32_t hs = s < N0 ? c->ht[s] : hnew[s - N0], ho = o < N0 ? c->ht[o] : hnew[o - N0];
+        hnew[i] = std::max(hs, ho) + 1;
+        hmax = std::max(hmax, hnew[i]);
+    }
+    const size_t b4 = (size_t)K * sizeof(int32_t);
+    HIPCHK(c, hipMemcpyAsync(c->d_cr.p + N0, creator, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_sp.p + N0, self_parent, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_op.p + N0, other_parent, b4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ht.p + N0, hnew.data(), b4, hipMemcpyHostToDevice, c->stream));
+    if (t) HIPCHK(c, hipMemcpyAsync(c->d_t.p + N0, t, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemsetAsync(c->d_t.p + N0, 0, (size_t)K * 8, c->stream));
+    if (sig64) HIPCHK(c, hipMemcpyAsync(c->d_sig.p + (size_t)N0 * 64, sig64, (size_t)K * 64, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemsetAsync(c->d_sig.p + (size_t)N0 * 64, 0, (size_t)K * 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_round.p + N0, 0xff, b4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->x_fam_ev.p + N0, 0xff, (size_t)K, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->x_tbd.p + N0, 1, (size_t)K, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cr.insert(c->cr.end(), creator, creator + K);
+    c->sp.insert(c->sp.end(), self_parent, self_parent + K);
+    c->op.insert(c->op.end(), other_parent, other_parent + K);
+    c->ht.insert(c->ht.end(), hnew.begin(), hnew.end());
+    c->max_height = hmax;
+    c->N = N0 + K;
+    return SW_OK;
+}
+
+int exact_divide(sw_ctx* c, int64_t first, int64_t K) {
+    CHK(ensure_rounds(c, c->max_height + 3));  // round <= height: every row a witness can land in exists
+    CHK(exact_grow(c));
+    CHK(exact_set_hdr(c, swx::H_RC, 0));
+    for (int64_t a = first; a < first + K; a += 8192) {  // (bounded launches: one wavefront walks the events in order)
+        const int64_t k = std::min<int64_t>(8192, first + K - a);
+        hipLaunchKernelGGL(k_exact_divide, dim3(1), dim3(64), 0, c->stream, exact_state(c), (long long)a, (long long)k);
+        c->ctr.kernel_launches++;
+    }
+    HIPCHK(c, hipGetLastError());
+    long long hdr[swx::H_WORDS];
+    CHK(exact_read_hdr(c, hdr));
+    if (hdr[swx::H_RC] != swx::X_OK) { c->poisoned = true; return fail(c, SW_EIO, "exact divide_rounds: a parent of event %lld has no round", hdr[swx::H_ERR_AT]); }
+    c->R = (int)hdr[swx::H_R];
+    c->divided = first + K;
+    c->ctr.events_divided += K;
+    c->ctr.rounds = c->R;
+    return SW_OK;
+}
+
+int exact_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
+    const int R = c->R, np = c->npad;
+    const int max_c = first_undecided_round(c);
+    swx::FameScratch x{};
+    x.win = std::max(1, R - max_c);
+    x.layer = (size_t)np * x.win * np;
+    if (x.layer > ((size_t)4 << 30)) return fail(c, SW_ENOMEM, "exact decide_fame: %d undecided rounds x %d members need %zu GB of vote storage", x.win, c->n, (2 * x.layer) >> 30);
+    CHK(exact_grow(c));
+    CHK(dgrow(c, c->x_votes, 2 * x.layer, 0));
+    x.votes = c->x_votes.p; x.s_m = c->x_sm.p; x.done = c->x_done.p; x.new_rounds = c->x_newr.p;
+    CHK(exact_set_hdr(c, swx::H_RC, 0));
+    CHK(exact_set_hdr(c, swx::H_NNEW, 0));
+    hipLaunchKernelGGL(k_exact_fame, dim3(1), dim3(64), 0, c->stream, exact_state(c), x);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    long long hdr[swx::H_WORDS];
+    CHK(exact_read_hdr(c, hdr));
+    if (hdr[swx::H_RC] != swx::X_OK)
+        return fail(c, SW_EINVAL, "exact decide_fame: a voter strongly sees a member without a witness in the previous round, or a vote is missing (KeyError in the reference, swirld.py:253 / 260)");
+    const int cnt = (int)hdr[swx::H_NNEW];
+    std::vector<int32_t> nr(std::max(cnt, 1));
+    if (cnt) {
+        HIPCHK(c, hipMemcpyAsync(nr.data(), c->x_newr.p, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    for (int i = 0; i < cnt; ++i) {
+        c->cons_h[nr[i]] = 1;
+        if (i < cap && new_rounds) new_rounds[i] = nr[i];
+    }
+    if (n_new) *n_new = cnt;
+    FameCounters fc{};
+    fc.voter_evals = (u64)hdr[swx::H_VOTER_EVALS] + c->x_fc_base.voter_evals;
+    fc.majority_evals = (u64)hdr[swx::H_MAJ_EVALS] + c->x_fc_base.majority_evals;
+    fc.coin_votes = (u64)hdr[swx::H_COIN_VOTES] + c->x_fc_base.coin_votes;
+    fc.coin_flips = (u64)hdr[swx::H_COIN_FLIPS] + c->x_fc_base.coin_flips;
+    fame_counters(c, fc);
+    if (cnt > cap) return fail(c, SW_ERANGE, "new_rounds capacity %d < %d", cap, cnt);
+    return SW_OK;
+}
+
+int exact_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, int64_t cap, int64_t* n_out) {
+    std::sort(rounds.begin(), rounds.end());  // sorted(new_c), swirld.py:283
+    rounds.erase(std::unique(rounds.begin(), rounds.end()), rounds.end());
+    const int nr = (int)rounds.size();
+    if (nr == 0) return SW_OK;
+    if (rounds.front() < 0 || rounds.back() >= c->R)
+        return fail(c, SW_ERANGE, "find_order: round outside [0, %d) (KeyError in the reference)", c->R);
+    CHK(exact_grow(c));
+    CHK(dgrow(c, c->x_rounds, nr, 0));
+    HIPCHK(c, hipMemcpyAsync(c->x_rounds.p, rounds.data(), (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    CHK(exact_set_hdr(c, swx::H_RC, 0));
+    CHK(exact_set_hdr(c, swx::H_NOUT, 0));
+    swx::OrderScratch x{};
+    x.queue = c->x_queue.p; x.visited = c->x_visited.p; x.fw = c->x_fw.p; x.sflag = c->x_sflag.p; x.times = c->x_times.p;
+    x.tsort = c->x_tsort.p; x.white = c->x_white.p; x.items_ev = c->x_items_ev.p; x.items_ts = c->x_items_ts.p;
+    hipLaunchKernelGGL(k_exact_order, dim3(1), dim3(64), 0, c->stream, exact_state(c), x, (const int*)c->x_rounds.p, nr);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    long long hdr[swx::H_WORDS];
+    CHK(exact_read_hdr(c, hdr));
+    if (hdr[swx::H_RC] == swx::X_EINDEX)
+        return fail(c, SW_ERANGE, "find_order: an event is seen by a single famous witness (IndexError at swirld.py:305)");
+    if (hdr[swx::H_RC] != swx::X_OK)
+        return fail(c, SW_EINVAL, "find_order: a round has an undecided witness (KeyError on self.famous[w], swirld.py:284)");
+    const int64_t produced = hdr[swx::H_NOUT];
+    const size_t at = c->transactions.size();
+    c->transactions.resize(at + (size_t)produced);
+    if (produced) {
+        HIPCHK(c, hipMemcpyAsync(c->transactions.data() + at, c->x_items_ev.p, (size_t)produced * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (n_out) *n_out = produced;
+    if (produced > cap) return fail(c, SW_ERANGE, "find_order: out_events capacity %lld < %lld", (long long)cap, (long long)produced);
+    if (out_events) memcpy(out_events, c->transactions.data() + at, (size_t)produced * sizeof(int32_t));
+    return SW_OK;
+}
+
+// state of the exact path back to "nothing divided" (sw_rewind; the events and their forks stay)
+int exact_rewind(sw_ctx* c) {
+    if (c->N) {
+        HIPCHK(c, hipMemsetAsync(c->x_fam_ev.p, 0xff, (size_t)c->N, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->x_tbd.p, 1, (size_t)c->N, c->stream));
+    }
+    if (c->x_Rcap) HIPCHK(c, hipMemsetAsync(c->x_wcnt.p, 0, (size_t)c->x_Rcap * sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->x_hdr.p, 0, swx::H_WORDS * sizeof(long long), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->x_fc_base = c->fc_seen;
+    return SW_OK;
 }
 
 // A Node's gossip step appends a handful of events: one packed record per event in pinned memory,
@@ -1823,6 +2083,7 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
     if (K < 0 || (K > 0 && (!creator || !self_parent || !other_parent))) return fail(c, SW_EINVAL, "NULL event arrays");
     if (K == 0) return SW_OK;
     if (c->N + K > 0x7ffffff0ll) return fail(c, SW_ERANGE, "more than 2^31 events");
+    if (c->exact) return append_exact(c, K, creator, self_parent, other_parent, t, sig64);
     const int64_t N0 = c->N;
     const int n = c->n;
     const bool bulk = K >= 8192 || c->chain_cap.empty() || K * 8 >= N0;
@@ -1843,6 +2104,9 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         if (head_t[m] != s) {
             if (s >= 0 && (s < N0 ? c->cr[s] : creator[s - N0]) != m)
                 return fail(c, SW_EINVAL, "event %lld: self-parent is by another member", (long long)e);
+            // a fork (the reference stores it, README.md:84): the context moves to the exact path, which
+            // validates the batch again on its own terms
+            if (c->forks_mode == 1 && !c->vm.active) return append_exact(c, K, creator, self_parent, other_parent, t, sig64);
             return fail(c, SW_ENOTSUP, "event %lld is a fork (member %d already has %s): forked hashgraphs are outside the "
                         "supported domain; nothing was stored", (long long)e, m, s < 0 ? "a root" : "a later event on that self-parent");
         }
@@ -1962,6 +2226,7 @@ int sw_divide_rounds(sw_ctx* c, int64_t first, int64_t K) {
     if (K == 0) return SW_OK;
     if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->exact) return exact_divide(c, first, K);
     switch (c->nw) {
         case 1: return do_divide<1>(c, first, K);
         case 2: return do_divide<2>(c, first, K);
@@ -1977,6 +2242,7 @@ int sw_decide_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
     if (n_new) *n_new = 0;
     if (c->R <= 0) return fail(c, SW_EINVAL, "decide_fame before any witness exists (max() of an empty dict in the reference, swirld.py:225)");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->exact) return exact_fame(c, new_rounds, cap, n_new);
     switch (c->nw) {
         case 1: return do_fame<1>(c, new_rounds, cap, n_new);
         case 2: return do_fame<2>(c, new_rounds, cap, n_new);
@@ -1991,6 +2257,7 @@ int sw_decide_fame_partial(sw_ctx* c, int part, int nparts, int8_t* famous, uint
     if (!c || !famous || !decided) return SW_EINVAL;
     if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
     if (nparts < 1 || part < 0 || part >= nparts) return fail(c, SW_EINVAL, "part %d of %d", part, nparts);
+    if (c->exact) return fail(c, SW_ENOTSUP, "sw_decide_fame_partial is not available on the exact (forked-hashgraph) path");
     if (c->R <= 0) return fail(c, SW_EINVAL, "decide_fame before any witness exists (max() of an empty dict in the reference, swirld.py:225)");
     if (r_out) *r_out = c->R;
     if (r_cap < c->R) return fail(c, SW_ERANGE, "famous / decided hold %d rounds, %d needed", r_cap, c->R);
@@ -2010,6 +2277,7 @@ int sw_commit_fame(sw_ctx* c, const int8_t* famous, const uint8_t* decided, int 
     if (n_new) *n_new = 0;
     if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
     if (R != c->R) return fail(c, SW_EINVAL, "merged table has %d rounds, the context %d", R, c->R);
+    if (c->exact) return fail(c, SW_ENOTSUP, "sw_commit_fame is not available on the exact (forked-hashgraph) path");
     HIPCHK(c, hipSetDevice(c->device));
     const int np = c->npad, n = c->n;
     const int max_c = first_undecided_round(c);
@@ -2093,6 +2361,49 @@ int sw_get_window(sw_ctx* c, int64_t* first_resident_event, int64_t* resident_by
     return SW_OK;
 }
 
+int sw_set_forks(sw_ctx* c, int accept) {
+    if (!c) return SW_EINVAL;
+    if (accept != 0 && accept != 1) return fail(c, SW_EINVAL, "sw_set_forks: 0 (refuse) or 1 (accept)");
+    c->forks_mode = accept;
+    return SW_OK;
+}
+
+int sw_get_exact(sw_ctx* c, int* out) {
+    if (!c || !out) return SW_EINVAL;
+    *out = c->exact ? 1 : 0;
+    return SW_OK;
+}
+
+// Members of witnesses[r] in dict insertion order (what iterating self.witnesses[r] yields, swirld.py:234, 240):
+// ascending event index of a member's FIRST witness of the round — which is the table entry unless a fork
+// sibling replaced it (exact path: kept explicitly).
+int sw_get_witness_order(sw_ctx* c, int r, int32_t* members, int* n_out) {
+    if (!c || !members || !n_out) return SW_EINVAL;
+    *n_out = 0;
+    if (r < 0 || r >= c->R) return fail(c, SW_ERANGE, "round %d outside [0, %d)", r, c->R);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int np = c->npad, n = c->n;
+    if (c->exact) {
+        int32_t cnt = 0;
+        std::vector<int32_t> row(np);
+        HIPCHK(c, hipMemcpyAsync(&cnt, c->x_wcnt.p + r, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(row.data(), c->x_worder.p + (size_t)r * np, np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < cnt; ++i) members[i] = row[i];
+        *n_out = cnt;
+        return SW_OK;
+    }
+    std::vector<int32_t> row(np);
+    HIPCHK(c, hipMemcpyAsync(row.data(), c->d_wit.p + (size_t)r * np, np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<std::pair<int32_t, int32_t>> ws;
+    for (int m = 0; m < n; ++m) if (row[m] >= 0) ws.push_back({row[m], m});
+    std::sort(ws.begin(), ws.end());
+    for (size_t i = 0; i < ws.size(); ++i) members[i] = ws[i].second;
+    *n_out = (int)ws.size();
+    return SW_OK;
+}
+
 int sw_rewind(sw_ctx* c) {
     if (!c) return SW_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2141,6 +2452,7 @@ int sw_rewind(sw_ctx* c) {
     c->sw_dirty_from = 1;
     c->transactions.clear();
     std::fill(c->ord_pos.begin(), c->ord_pos.end(), 0);
+    if (c->exact) CHK(exact_rewind(c));
     return SW_OK;
 }
 
@@ -2162,6 +2474,7 @@ int sw_reset(sw_ctx* c) {
     c->pool_h_valid = true;
     if (c->stream_io) HIPCHK(c, hipStreamSynchronize(c->stream_io));  // a payload upload may still be writing t / sig
     c->payload_pending = false;
+    c->exact = false;  // (a fresh hashgraph starts on the fast path again)
     return SW_OK;
 }
 
@@ -2171,6 +2484,7 @@ int sw_find_order(sw_ctx* c, const int32_t* rounds, int n_rounds, int32_t* out_e
     if (n_rounds < 0 || (n_rounds > 0 && !rounds)) return fail(c, SW_EINVAL, "find_order: NULL rounds");
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<int32_t> rs(rounds, rounds + n_rounds);
+    if (c->exact) return exact_order(c, rs, out_events, cap, n_out);
     switch (c->nw) {
         case 1: return do_find_order<1>(c, rs, out_events, cap, n_out);
         case 2: return do_find_order<2>(c, rs, out_events, cap, n_out);
@@ -2248,6 +2562,7 @@ int sw_get_sees_mask(sw_ctx* c, int64_t first, int64_t K, uint64_t* out) {
     if (!c || !out) return SW_EINVAL;
     if (first < 0 || K < 0 || first + K > c->divided) return fail(c, SW_ERANGE, "range outside the divided events");
     if (!K) return SW_OK;
+    if (c->exact) return fail(c, SW_ENOTSUP, "sw_get_sees_mask is not available on the exact (forked-hashgraph) path");
     HIPCHK(c, hipSetDevice(c->device));
     const int nw = c->nw, nwo = (c->n + 63) / 64;
     std::vector<u64> tmp((size_t)K * nw);
@@ -2275,6 +2590,7 @@ int sw_get_sees_mask(sw_ctx* c, int64_t first, int64_t K, uint64_t* out) {
 int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
     if (!c || !out) return SW_EINVAL;
     *out = -1;
+    if (c->exact) return fail(c, SW_ENOTSUP, "sw_get_vote is not available on the exact (forked-hashgraph) path");
     const int np = c->npad, nw = c->nw, n = c->n;
     if (rc < 0 || rv >= c->R || mv < 0 || mv >= n || mc < 0 || mc >= n) return fail(c, SW_ERANGE, "witness slot outside the table");
     if (rv <= rc) return SW_OK;
@@ -2354,6 +2670,7 @@ int sw_get_known_heights(sw_ctx* c, int64_t head_event, int32_t* out) {
 
 int sw_sync_diff(sw_ctx* c, int64_t head_event, const int32_t* known_height, int32_t* pos_first, int32_t* pos_end, int64_t* n_events) {
     if (!c || !known_height || !pos_first || !pos_end) return SW_EINVAL;
+    if (c->exact) return fail(c, SW_ENOTSUP, "sw_sync_diff is not available on the exact (forked-hashgraph) path");
     if (head_event < c->first_resident || head_event >= c->divided) return fail(c, SW_ERANGE, "head %lld is not a divided, resident event", (long long)head_event);
     HIPCHK(c, hipSetDevice(c->device));
     CHK(ensure_dag_h(c));
@@ -2380,6 +2697,7 @@ int sw_sync_diff(sw_ctx* c, int64_t head_event, const int32_t* known_height, int
 
 int sw_get_chain_events(sw_ctx* c, int member, int32_t p0, int32_t p1, int32_t* out) {
     if (!c || !out) return SW_EINVAL;
+    if (c->exact) return fail(c, SW_ENOTSUP, "sw_get_chain_events is not available on the exact (forked-hashgraph) path");
     if (member < 0 || member >= c->n || p0 < 0 || p1 < p0 || p1 > c->nev[member]) return fail(c, SW_ERANGE, "chain positions [%d, %d) of member %d", p0, p1, member);
     if (p1 == p0) return SW_OK;
     HIPCHK(c, hipSetDevice(c->device));

@@ -137,6 +137,13 @@ class Hashgraph:
         self._chk(self._L.sw_get_witnesses(self._h, r0, r1, _p(out)))
         return out
 
+    def witness_order(self, r):
+        """Members of witnesses[r] in dict insertion order (swirld.py:234, 240)."""
+        out = np.empty(self.n, np.int32)
+        k = C.c_int(0)
+        self._chk(self._L.sw_get_witness_order(self._h, int(r), _p(out), C.byref(k)))
+        return out[:k.value].copy()
+
     def famous(self, r0=0, r1=None):
         r1 = self.max_round + 1 if r1 is None else r1
         out = np.empty((max(r1 - r0, 0), self.n), np.int8)
@@ -205,6 +212,18 @@ class Hashgraph:
         out = np.zeros((4096, 32), np.uint64)
         self._chk(self._L.sw_debug_clocks(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
+
+    def set_forks(self, accept=True):
+        """Forked events: accepted (the context moves to the exact path, csrc/exact.hip.h — the reference's
+        statements on the device, identical results, far slower) or refused with SW_ENOTSUP."""
+        self._chk(self._L.sw_set_forks(self._h, 1 if accept else 0))
+
+    @property
+    def exact(self):
+        """True once a forked event moved the context to the exact path."""
+        v = C.c_int(0)
+        self._chk(self._L.sw_get_exact(self._h, C.byref(v)))
+        return bool(v.value)
 
     def set_window(self, enable=True, chunk_mb=0):
         """Windowed can_see table (before the first append): rows no later call can read are evicted

@@ -102,7 +102,10 @@ class _WitnessView(Mapping):
         if not 0 <= r < tab.shape[0]:
             return {}  # the reference's defaultdict would create an empty dict
         row = tab[r]
-        order = [c for c in np.argsort(np.where(row >= 0, row, np.iinfo(np.int32).max), kind="stable") if row[c] >= 0]
+        if self._n._dev.exact:  # forks: a sibling replaces a member's witness but keeps its dict position
+            order = [int(c) for c in self._n._dev.witness_order(r)]
+        else:
+            order = [c for c in np.argsort(np.where(row >= 0, row, np.iinfo(np.int32).max), kind="stable") if row[c] >= 0]
         return {self._n._members[c]: self._n._ids[row[c]] for c in order}
 
     def __iter__(self):
@@ -207,8 +210,13 @@ class Node:
     # the host (one signature costs a GPU thread ~1-2 ms of latency, a CPU core ~60 us).  None = never.
     device_crypto_threshold = 512
 
-    def __init__(self, kp, network, n_nodes, stake, device=0):
+    def __init__(self, kp, network, n_nodes, stake, device=0, accept_forks=False):
         self.pk, self.sk = kp
+        # Forked events (two events of a member on one self-parent; the reference stores them, README.md:84).
+        # False [default]: dropped in is_valid_event — an honest node keeps its round-synchronous device
+        # path.  True: stored as in the reference; the device context then moves to the exact path
+        # (csrc/exact.hip.h: identical results, one wavefront — a single Byzantine fork slows this node down).
+        self.accept_forks = bool(accept_forks)
         self.network = network  # {pk -> Node.ask_sync}
         self.n = n_nodes
         self.stake = stake
@@ -237,6 +245,7 @@ class Node:
         self._divided = 0
         self._device = device
         self._dev = Hashgraph(n_nodes, [stake[pk] for pk in self._members], coin_period=C, device=device)
+        self._dev.set_forks(self.accept_forks)
         self._round_cache = np.zeros(0, np.int32)
         self._wit_cache = None
         self._fam_cache = None
@@ -285,7 +294,7 @@ class Node:
         (or a second root) is rejected, and with it everything built on top of it.  The device path
         needs one self-parent chain per member; dropping the fork keeps an honest node running
         where storing it would make every later divide_rounds fail."""
-        if h in self.hg:  # already accepted (sync re-validates the remote head, swirld.py:138)
+        if self.accept_forks or h in self.hg:  # (already accepted: sync re-validates the remote head, swirld.py:138)
             return True
         return self._chain_head.get(ev.c) == (ev.p[0] if ev.p else None)
 

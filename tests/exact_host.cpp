@@ -1,0 +1,130 @@
+// Host build of exact.hip.h (g++ -DSW_EXACT_HOST) — TEST INFRASTRUCTURE: lets the CPU suite run the very
+// functions the exact (forked-hashgraph) kernels execute against the oracle (tests/test_exact_host.py).
+// The product never loads this library; it launches the kernels of swirld_hip.hip.
+#define SW_EXACT_HOST 1
+#include "../py-swirld_amd/csrc/exact.hip.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+struct Ctx {
+    int n, np, C;
+    std::vector<uint32_t> stake;
+    uint64_t tot = 0;
+    std::vector<int> cr, sp, op, ht, round, L, wit, worder, wcnt, tx;
+    std::vector<double> t;
+    std::vector<unsigned char> sig, tbd, cons;
+    std::vector<signed char> fam_ev, fam_slot;
+    long long hdr[swx::H_WORDS];
+    int Rcap = 0;
+    long long N = 0;
+    swx::State state() {
+        swx::State s{};
+        s.n = n; s.npad = np; s.coin_period = C; s.tot = tot; s.stake = stake.data();
+        s.cr = cr.data(); s.sp = sp.data(); s.op = op.data(); s.ht = ht.data(); s.t = t.data(); s.sig = sig.data();
+        s.round = round.data(); s.L = L.data(); s.tbd = tbd.data(); s.fam_ev = fam_ev.data();
+        s.Rcap = Rcap; s.wit = wit.data(); s.worder = worder.data(); s.wcnt = wcnt.data(); s.cons = cons.data();
+        s.fam_slot = fam_slot.data(); s.hdr = hdr;
+        return s;
+    }
+    void rounds(int need) {
+        if (need <= Rcap) return;
+        wit.resize((size_t)need * np, -1); worder.resize((size_t)need * np, 0); wcnt.resize(need, 0);
+        cons.resize(need, 0); fam_slot.resize((size_t)need * np, -1);
+        Rcap = need;
+    }
+};
+}  // namespace
+
+extern "C" {
+void* swx_host_create(int n, const uint32_t* stake, int coin_period) {
+    Ctx* c = new Ctx;
+    c->n = n; c->np = (n + 63) / 64 * 64; c->C = coin_period;
+    c->stake.assign(c->np, 0);
+    for (int i = 0; i < n; ++i) { c->stake[i] = stake[i]; c->tot += stake[i]; }
+    memset(c->hdr, 0, sizeof c->hdr);
+    return c;
+}
+void swx_host_destroy(void* p) { delete (Ctx*)p; }
+int swx_host_append(void* p, long long K, const int* cr, const int* sp, const int* op, const double* t, const unsigned char* sig) {
+    Ctx* c = (Ctx*)p;
+    int hmax = 0;
+    for (long long i = 0; i < K; ++i) {
+        c->cr.push_back(cr[i]); c->sp.push_back(sp[i]); c->op.push_back(op[i]);
+        c->ht.push_back(sp[i] < 0 ? 0 : std::max(c->ht[sp[i]], c->ht[op[i]]) + 1);
+        c->t.push_back(t ? t[i] : 0.0);
+        for (int b = 0; b < 64; ++b) c->sig.push_back(sig ? sig[64 * i + b] : 0);
+        c->round.push_back(-1); c->tbd.push_back(1); c->fam_ev.push_back(-1);
+    }
+    c->N += K;
+    c->L.resize((size_t)c->N * c->np, -1);
+    for (int h : c->ht) hmax = std::max(hmax, h);
+    c->rounds(hmax + 3);
+    return 0;
+}
+int swx_host_divide(void* p, long long first, long long K) {
+    Ctx* c = (Ctx*)p;
+    c->hdr[swx::H_RC] = 0;
+    return swx::divide(c->state(), first, K);
+}
+int swx_host_fame(void* p, int* new_rounds, int* n_new) {
+    Ctx* c = (Ctx*)p;
+    c->hdr[swx::H_RC] = 0; c->hdr[swx::H_NNEW] = 0;
+    const int R = (int)c->hdr[swx::H_R];
+    int max_c = 0;
+    while (max_c < R && c->cons[max_c]) ++max_c;
+    swx::FameScratch x{};
+    x.win = std::max(1, R - max_c);
+    x.layer = (size_t)c->np * x.win * c->np;
+    std::vector<signed char> votes(2 * x.layer);
+    std::vector<unsigned char> s_m(c->np), done(c->Rcap);
+    std::vector<int> nr(c->Rcap);
+    x.votes = votes.data(); x.s_m = s_m.data(); x.done = done.data(); x.new_rounds = nr.data();
+    const int rc = swx::decide_fame(c->state(), x);
+    *n_new = (int)c->hdr[swx::H_NNEW];
+    for (int i = 0; i < *n_new; ++i) new_rounds[i] = nr[i];
+    return rc;
+}
+int swx_host_order(void* p, const int* rounds, int n_rounds, int* out, long long* n_out) {
+    Ctx* c = (Ctx*)p;
+    c->hdr[swx::H_RC] = 0; c->hdr[swx::H_NOUT] = 0;
+    std::vector<int> rs(rounds, rounds + n_rounds);
+    std::sort(rs.begin(), rs.end());
+    swx::OrderScratch x{};
+    std::vector<int> queue(c->N + 1), fw(c->np), items_ev(c->N + 1);
+    std::vector<unsigned char> visited(c->N + 1, 0), sflag(c->np), white(64);
+    std::vector<double> times(c->np), tsort(c->np), items_ts(c->N + 1);
+    x.queue = queue.data(); x.visited = visited.data(); x.fw = fw.data(); x.sflag = sflag.data(); x.times = times.data();
+    x.tsort = tsort.data(); x.white = white.data(); x.items_ev = items_ev.data(); x.items_ts = items_ts.data();
+    const int rc = swx::find_order(c->state(), x, rs.data(), n_rounds);
+    *n_out = c->hdr[swx::H_NOUT];
+    for (long long i = 0; i < *n_out; ++i) { out[i] = items_ev[i]; c->tx.push_back(items_ev[i]); }
+    return rc;
+}
+// getters
+int swx_host_R(void* p) { return (int)((Ctx*)p)->hdr[swx::H_R]; }
+void swx_host_get(void* p, int* round, int* L, int* wit, int* worder, int* wcnt, unsigned char* cons, signed char* fam_ev, unsigned char* tbd, signed char* fam_slot) {
+    Ctx* c = (Ctx*)p;
+    const int R = (int)c->hdr[swx::H_R];
+    memcpy(round, c->round.data(), c->N * sizeof(int));
+    for (long long e = 0; e < c->N; ++e) memcpy(L + e * c->n, c->L.data() + e * c->np, c->n * sizeof(int));
+    for (int r = 0; r < R; ++r) {
+        memcpy(wit + (size_t)r * c->n, c->wit.data() + (size_t)r * c->np, c->n * sizeof(int));
+        memcpy(worder + (size_t)r * c->n, c->worder.data() + (size_t)r * c->np, c->n * sizeof(int));
+        memcpy(fam_slot + (size_t)r * c->n, c->fam_slot.data() + (size_t)r * c->np, c->n);
+        wcnt[r] = c->wcnt[r]; cons[r] = c->cons[r];
+    }
+    memcpy(fam_ev, c->fam_ev.data(), c->N);
+    memcpy(tbd, c->tbd.data(), c->N);
+}
+// a context that ran fork-free so far: witness order / fame per event / tbd rebuilt from the per-slot tables
+void swx_host_import_check(void* p) {
+    Ctx* c = (Ctx*)p;
+    std::vector<int> worder0(c->worder), wcnt0(c->wcnt);
+    std::vector<signed char> fam0(c->fam_ev);
+    std::vector<unsigned char> tbd0(c->tbd);
+    swx::import_fast_state(c->state(), c->N, c->tx.data(), (long long)c->tx.size());
+}
+}

@@ -13,7 +13,21 @@ class OracleHashgraph:
         self._o = Oracle(n_members, None if stake is None else np.asarray(stake, np.uint64), coin_period)
 
     def append_events(self, creator, self_parent, other_parent, t=None, sig=None):
+        head = self.__dict__.setdefault("_head", {})
+        base = self._o.N
+        for i, (m, s_) in enumerate(zip(np.asarray(creator).tolist(), np.asarray(self_parent).tolist())):
+            if head.get(m, -1) != s_:  # a fork: the real engine moves to its exact path here
+                self.exact = True
+            head[m] = base + i
         self._o.append_events(creator, self_parent, other_parent, t, sig)
+
+    exact = False
+
+    def set_forks(self, accept=True):
+        self._accept_forks = bool(accept)
+
+    def witness_order(self, r):
+        return self._o.witness_order(r)
 
     @property
     def num_events(self):

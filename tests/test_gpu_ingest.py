@@ -29,6 +29,7 @@ def test_bulk_append_is_atomic_on_rejection(pkg):
         h.append_events(cr, sp, bad, t, sig)
     assert ei.value.code == -22 and str(k) in str(ei.value)
     assert h.num_events == 0
+    h.set_forks(False)                               # (accepted by default: tests/test_gpu_forks.py)
     fork = sp.copy()
     j = int(np.nonzero(cr[n:] == cr[n + 5])[0][3]) + n  # a later event of that member: point it at an older self-parent
     fork[j] = sp[sp[j]]

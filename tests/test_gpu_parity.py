@@ -117,8 +117,10 @@ def test_votes_match_reference_incremental_schedules(pkg, name):
 
 
 def test_fork_is_refused(pkg):
+    """sw_set_forks(0): what a Node that drops forked events runs with (default: accepted, tests/test_gpu_forks.py)."""
     g = load_golden("n8_s11_forks")
     h = pkg.Hashgraph(g["n"])
+    h.set_forks(False)
     cr, sp, op = g["creator"], g["self_parent"], g["other_parent"]
     with pytest.raises(pkg.SwirldHipError) as ei:
         h.append_events(cr, sp, op, g["t"], g["sig"])

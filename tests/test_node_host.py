@@ -102,3 +102,29 @@ def test_forked_events_are_dropped_not_stored(pkg, monkeypatch):
     # a second root of a member is a fork too
     hr, er = b.new_event(None, ())
     assert not a.is_valid_event(hr, er)
+
+
+def test_forked_events_are_stored_with_accept_forks(pkg, monkeypatch):
+    """accept_forks=True: the reference's behaviour (both siblings stored, the later one replaces the
+    member's witness but keeps its dict position); host logic on the oracle backend."""
+    monkeypatch.setattr(pkg.node, "Hashgraph", oracle_backend.OracleHashgraph)
+    crypto = pkg.node.crypto
+    kpa, kpb = crypto.sign_keypair(), crypto.sign_keypair()
+    stake = {kpa[0]: 1, kpb[0]: 1}
+    a = pkg.Node(kpa, {}, 2, stake, accept_forks=True)
+    b = pkg.Node(kpb, {}, 2, stake, accept_forks=True)
+    ra, rb = a.head, b.head
+    a.add_event(rb, b.hg[rb])
+    b.add_event(ra, a.hg[ra])
+    h1, e1 = b.new_event(b"one", (rb, ra))
+    h2, e2 = b.new_event(b"two", (rb, ra))      # a fork of member b
+    assert a.is_valid_event(h1, e1) and a.is_valid_event(h2, e2)
+    a.add_event(h1, e1)
+    a.add_event(h2, e2)
+    hr, er = b.new_event(None, ())              # a second root of b
+    assert a.is_valid_event(hr, er)
+    a.add_event(hr, er)
+    a.divide_rounds((rb, h1, h2, hr))
+    assert a._dev.exact
+    assert a.round[h1] == a.round[h2] == a.round[hr] == 0
+    assert list(a.witnesses[0]) == [kpa[0], kpb[0]] and a.witnesses[0][kpb[0]] == hr   # replaced value, kept position
