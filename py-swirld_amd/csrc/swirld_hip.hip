@@ -1583,6 +1583,18 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
             CHIP(hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking));
             CHIP(hipStreamCreateWithFlags(&c->stream_io, hipStreamNonBlocking));
         }
+        // experiment (SW_CS_CUS=<count>): confine the can_see sweeps to the first <count> compute units of
+        // the CU mask, so that the round loop's kernels find the others free of polling waves
+        if (const char* e = getenv("SW_CS_CUS")) {
+            const int cus = atoi(e);
+            if (cus > 0 && cus < 256) {
+                uint32_t mask[8] = {0};
+                for (int i = 0; i < cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+                hipStream_t s2 = nullptr;
+                if (hipExtStreamCreateWithCUMask(&s2, 8, mask) == hipSuccess) { (void)hipStreamDestroy(c->stream_cs); c->stream_cs = s2; }
+                else (void)hipGetLastError();
+            }
+        }
         CHIP(hipEventCreateWithFlags(&c->ev_payload, hipEventDisableTiming));
         CHIP(hipEventCreateWithFlags(&c->ev_small, hipEventDisableTiming));
     }

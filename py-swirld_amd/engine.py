@@ -17,9 +17,21 @@ class Hashgraph:
     def __init__(self, n_members, stake=None, coin_period=6, device=0):
         self._L = _lib.load()
         self.n = int(n_members)
-        st = np.ones(self.n, np.uint64) if stake is None else np.ascontiguousarray(stake, np.uint64)
-        if st.shape != (self.n,):
-            raise ValueError("stake must have one entry per member")
+        if stake is None:
+            st = np.ones(self.n, np.uint64)
+        else:
+            raw = np.asarray(stake)
+            if raw.shape != (self.n,):
+                raise ValueError("stake must have one entry per member")
+            # the reference compares sums of stakes with 2*tot/3 in Python arithmetic (swirld.py:41-44); the
+            # device tallies are integer: non-integer, negative or non-finite stakes are refused, not truncated
+            if raw.dtype.kind not in "iu":
+                as_f = raw.astype(np.float64)
+                if not np.all(np.isfinite(as_f)) or np.any(as_f != np.floor(as_f)):
+                    raise ValueError("stakes must be integers (got %r)" % (raw.tolist(),))
+            if np.any(raw.astype(np.float64) < 0):
+                raise ValueError("stakes must be non-negative")
+            st = np.ascontiguousarray(raw, np.uint64)
         self.stake = st
         self._h = C.c_void_p()
         rc = self._L.sw_create(self.n, _p(st), int(coin_period), int(device), C.byref(self._h))

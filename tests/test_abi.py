@@ -81,3 +81,10 @@ def test_no_cpu_fallback(pkg):
     with pytest.raises(pkg.SwirldHipError) as ei:
         pkg.Hashgraph(4)
     assert ei.value.code == -19  # SW_ENODEV
+
+
+def test_stakes_are_validated_before_the_device_is_touched(pkg):
+    """Non-integer / negative stakes are refused (the device tallies are integer), not truncated."""
+    for bad in ([1, 2.5, 1, 1], [1, -1, 1, 1], [1, float("nan"), 1, 1], [1, 1, 1]):
+        with pytest.raises(ValueError):
+            pkg.Hashgraph(4, bad)
