@@ -146,10 +146,10 @@ SWX_HD inline int divide(const State& s, long long first, long long K) {
 }
 
 // Scratch of decide_fame: two layers of votes (the voters of round r_-1 and of round r_), indexed
-// [layer][voter member][(r - max_c) * npad + candidate member]; -1 = no entry (KeyError).
+// [layer][voter member][(r - max_c) * n + candidate member]; -1 = no entry (KeyError).
 struct FameScratch {
-    signed char* votes;     // [2][npad][win * npad]
-    size_t layer;           // npad * win * npad
+    signed char* votes;     // [2][n][win * n]
+    size_t layer;           // n * win * n
     int win;                // candidate rounds max_c .. max_c + win - 1
     unsigned char* s_m;     // [npad]
     unsigned char* done;    // [Rcap]
@@ -167,7 +167,7 @@ SWX_HD inline int decide_fame(const State& s, const FameScratch& x) {
     for (int r = lane; r < R; r += Wave::nl) x.done[r] = 0;
     for (size_t i = lane; i < 2 * x.layer; i += Wave::nl) x.votes[i] = -1;
     Wave::sync();
-    const size_t vrow = (size_t)x.win * np;
+    const size_t vrow = (size_t)x.win * n;
     for (int r_ = max_c + 1; r_ <= max_r; ++r_) {  // iter_voters, :238-241
         signed char* cur = x.votes + (size_t)(r_ & 1) * x.layer;
         const signed char* prev = x.votes + (size_t)((r_ & 1) ^ 1) * x.layer;
@@ -204,7 +204,7 @@ SWX_HD inline int decide_fame(const State& s, const FameScratch& x) {
                     const int xev = s.wit[(size_t)r * np + cx];
                     if (s.fam_ev[xev] >= 0) continue;  // :235
                     const int d = r_ - r;
-                    signed char* slot = cur + (size_t)cy * vrow + (size_t)(r - max_c) * np + cx;
+                    signed char* slot = cur + (size_t)cy * vrow + (size_t)(r - max_c) * n + cx;
                     if (d == 1) {  // :257-258: x in s
                         if (lane == 0) *slot = x.s_m[cx] && s.wit[(size_t)(r_ - 1) * np + cx] == xev;
                     } else {
@@ -212,7 +212,7 @@ SWX_HD inline int decide_fame(const State& s, const FameScratch& x) {
                         for (int c = lane; c < n; c += Wave::nl) {
                             if (!x.s_m[c]) continue;
                             const int w = s.wit[(size_t)(r_ - 1) * np + c];
-                            const signed char vw = prev[(size_t)c * vrow + (size_t)(r - max_c) * np + cx];
+                            const signed char vw = prev[(size_t)c * vrow + (size_t)(r - max_c) * n + cx];
                             if (vw < 0) miss = 1;
                             else if (vw) h1 += s.stake[s.cr[w]];
                             else h0 += s.stake[s.cr[w]];

@@ -1899,11 +1899,11 @@ int exact_divide(sw_ctx* c, int64_t first, int64_t K) {
 }
 
 int exact_fame(sw_ctx* c, int32_t* new_rounds, int cap, int* n_new) {
-    const int R = c->R, np = c->npad;
+    const int R = c->R;
     const int max_c = first_undecided_round(c);
     swx::FameScratch x{};
     x.win = std::max(1, R - max_c);
-    x.layer = (size_t)np * x.win * np;
+    x.layer = (size_t)c->n * x.win * c->n;
     if (x.layer > ((size_t)4 << 30)) return fail(c, SW_ENOMEM, "exact decide_fame: %d undecided rounds x %d members need %zu GB of vote storage", x.win, c->n, (2 * x.layer) >> 30);
     CHK(exact_grow(c));
     CHK(dgrow(c, c->x_votes, 2 * x.layer, 0));

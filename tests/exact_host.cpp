@@ -77,7 +77,7 @@ int swx_host_fame(void* p, int* new_rounds, int* n_new) {
     while (max_c < R && c->cons[max_c]) ++max_c;
     swx::FameScratch x{};
     x.win = std::max(1, R - max_c);
-    x.layer = (size_t)c->np * x.win * c->np;
+    x.layer = (size_t)c->n * x.win * c->n;
     std::vector<signed char> votes(2 * x.layer);
     std::vector<unsigned char> s_m(c->np), done(c->Rcap);
     std::vector<int> nr(c->Rcap);

@@ -46,6 +46,9 @@ def test_hip_matches_reference_golden(pkg, name):
     run_schedule(h, g)
     assert np.array_equal(h.heights(), g["height"])
     assert_state_equal(h, g["round"], g["can_see"], g["witnesses"], g["famous"], g["consensus"])
+    for r, order in enumerate(g["wit_order"]):   # iteration order of self.witnesses[r] (swirld.py:234, 240)
+        assert np.array_equal(h.witness_order(r), order), "dict order of witnesses[%d]" % r
+    assert not h.exact
     h.close()
 
 
