@@ -310,7 +310,7 @@ SWX_HD inline void sort_items(const State& s, const OrderScratch& x, long long b
 // Node.find_order(new_c), swirld.py:280-311; `rounds` sorted by the host (sorted() at :283).
 // hdr[H_NOUT] = number of events received, items_ev[0 .. H_NOUT) = their final order.
 SWX_HD inline int find_order(const State& s, const OrderScratch& x, const int* rounds, int n_rounds) {
-    const int n = s.n, np = s.npad, lane = Wave::lane();
+    const int np = s.npad, lane = Wave::lane();
     const int R = (int)s.hdr[H_R];
     long long produced = 0;
     for (int ir = 0; ir < n_rounds; ++ir) {

@@ -449,16 +449,6 @@ float span_ms(const Span& s) {
 // owns a segment of a pool, chain_ev[chain_start[m] + p] = its p-th event.  Segments have slack
 // and grow geometrically (a full segment moves to the end of the pool), so appending events
 // costs O(new events), not O(all events); bulk appends rebuild the pool compactly.
-int upload_chain_index(sw_ctx* c) {
-    const int np = c->npad;
-    HIPCHK(c, hipMemcpyAsync(c->d_chain_start.p, c->chain_start_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    std::vector<int32_t> cnt(np, 0);
-    std::copy(c->nev.begin(), c->nev.end(), cnt.begin());
-    HIPCHK(c, hipMemcpyAsync(c->d_chain_cnt.p, cnt.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SW_OK;
-}
-
 // Chain pool entries and chain descriptors of the events [first, first + K): one device pass over
 // cr / sp / op / seq with the CURRENT segment offsets (no host loop, no pool upload).
 int scatter_chains(sw_ctx* c, int64_t first, int64_t K) {
