@@ -230,6 +230,15 @@ def main():
                                   "(sequential C restatement of swirld.py:187-277), %.1f s" % (M, tc),
                         "python_reference_note": "the unmodified pure-Python reference cannot travel to the GPU box; in the "
                                                  "authoring container it runs 204 events/s at 256 members (BASELINE.md §3)"}
+        try:  # the reference itself, timed in the authoring container on a prefix of this very stream and compared
+            # with the oracle there (profiles/time_reference_here.py): a committed measurement, not a run of this job
+            with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
+                rp = json.load(f)
+            cpu_baseline["reference_python"] = {k: rp[k] for k in ("events_per_s", "events", "members", "cores", "cpu", "where",
+                                                                   "c_oracle_same_prefix_events_per_s",
+                                                                   "reference_equals_oracle_on_this_prefix") if k in rp}
+        except (OSError, ValueError):
+            pass
 
     if rank == 0:
         out = {

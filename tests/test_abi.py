@@ -88,3 +88,17 @@ def test_stakes_are_validated_before_the_device_is_touched(pkg):
     for bad in ([1, 2.5, 1, 1], [1, -1, 1, 1], [1, float("nan"), 1, 1], [1, 1, 1]):
         with pytest.raises(ValueError):
             pkg.Hashgraph(4, bad)
+
+
+def test_committed_measurement_fixtures_bench_reads():
+    """bench.py copies two committed measurements into its JSON line: the per-kernel HBM traffic of a
+    same-code rocprofv3 --pmc run and the timing of the unmodified Python reference (authoring container)."""
+    import json
+    import os
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        tr = json.load(f)
+    assert tr["commit"] and tr["kernels"]["k_cansee_flow"] > 0
+    with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
+        rp = json.load(f)
+    assert rp["reference_equals_oracle_on_this_prefix"] is True and rp["members"] == 256 and rp["events_per_s"] > 0
