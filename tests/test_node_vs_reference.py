@@ -150,3 +150,88 @@ def test_is_valid_event_agrees_with_reference(pkg, monkeypatch):
         assert o0.is_valid_event(h, mine) == want, name
         seen.add(want)
     assert seen == {True, False}
+
+
+@pytest.mark.parametrize("n,steps,seed,n_forks", [(4, 260, 31, 6), (5, 400, 32, 10), (3, 150, 33, 4)])
+def test_forked_hashgraph_matches_reference_node(pkg, monkeypatch, n, steps, seed, n_forks):
+    """A Byzantine member forks (two events on one self-parent, later events on either sibling).  The
+    unmodified reference class stores both (README.md:84); so does the drop-in with accept_forks=True —
+    and one observer of each kind, fed the same events in the same order and calling
+    divide_rounds / decide_fame / find_order on the same schedule, must agree on every view: rounds,
+    witnesses in dict order (a sibling replaces the value, not the position), fame, consensus,
+    can_see of the head, the total order."""
+    sw = refharness.import_reference()
+    import pysodium
+    monkeypatch.setattr(pkg.node, "Hashgraph", oracle_backend.OracleHashgraph)
+    monkeypatch.setattr(pkg.node, "dumps", _class_free_dumps)
+    monkeypatch.setattr(sw, "dumps", _class_free_dumps)
+    monkeypatch.setattr(sw, "time", _clock())
+    monkeypatch.setattr(pkg.node, "time", _clock())
+    kps = [pysodium.crypto_sign_seed_keypair(bytes([40 + i]) * 32) for i in range(n)]
+    stake = {kp[0]: 1 for kp in kps}
+    ref = [sw.Node(kp, {}, n, stake) for kp in kps]
+    ours = [pkg.Node(kp, {}, n, stake, accept_forks=True) for kp in kps]
+    assert [nd.head for nd in ref] == [nd.head for nd in ours]
+    obs_r, obs_o = ref[0], ours[0]                       # member 0 observes; everybody creates events
+    rng = random.Random(seed)
+    latest = {i: [ref[i].head] for i in range(n)}        # per member: tips it may build on (two after a fork)
+    pending = []
+    for i in range(1, n):                                # the observer learns the other roots
+        obs_r.add_event(ref[i].head, ref[i].hg[ref[i].head])
+        obs_o.add_event(ours[i].head, ours[i].hg[ours[i].head])
+        pending.append(ref[i].head)
+    for a, b in zip(ref, ours):                          # every creator knows every root (it signs on top of them)
+        for i in range(n):
+            if ref[i].head not in a.hg:
+                a.add_event(ref[i].head, ref[i].hg[ref[i].head])
+                b.add_event(ours[i].head, ours[i].hg[ours[i].head])
+    fork_steps = set(rng.sample(range(10, steps - 10), n_forks))
+    byz = n - 1
+    known = list(pending) + [obs_r.head]
+
+    def create(x, sp, op, payload):
+        hr, er = ref[x].new_event(payload, (sp, op))
+        ho, eo = ours[x].new_event(payload, (sp, op))
+        assert hr == ho, "same keys, clock and serialisation: same event ids"
+        for nd, ev in [(m, er) for m in ref] + [(m, eo) for m in ours]:
+            if hr not in nd.hg:
+                assert nd.is_valid_event(hr, ev)
+                nd.add_event(hr, ev)
+        pending.append(hr)
+        return hr
+
+    for step in range(steps):
+        x = byz if step in fork_steps else rng.randrange(n)
+        y = rng.choice([m for m in range(n) if m != x])
+        sp = rng.choice(latest[x])
+        op = rng.choice(latest[y])
+        h1 = create(x, sp, op, b"p%d" % step)
+        if step in fork_steps:                            # the sibling: same self-parent, another other-parent
+            y2 = rng.choice([m for m in range(n) if m != x])
+            h2 = create(x, sp, rng.choice(latest[y2]), b"q%d" % step)
+            latest[x] = [h1, h2]
+        else:
+            latest[x] = [h1] if rng.random() < 0.7 else (latest[x] + [h1])[-2:]
+        if step % 7 == 6 or step == steps - 1:            # the observers' main()-style call
+            if latest[0][-1] in obs_r.hg:
+                obs_r.head = obs_o.head = latest[0][-1]
+            obs_r.divide_rounds(list(pending))
+            obs_o.divide_rounds(list(pending))
+            pending.clear()
+            with contextlib.redirect_stdout(io.StringIO()):
+                ncr, nco = obs_r.decide_fame(), obs_o.decide_fame()
+                assert ncr == nco, "new_c at step %d" % step
+                obs_r.find_order(ncr)
+                obs_o.find_order(nco)
+            assert obs_r.transactions == obs_o.transactions, "total order at step %d" % step
+    assert obs_o._dev.exact
+    assert {h: obs_r.round[h] for h in obs_r.hg} == {h: obs_o.round[h] for h in obs_o.hg}
+    assert max(obs_r.round.values()) >= 3
+    rw = {r: list(d.items()) for r, d in obs_r.witnesses.items() if d}
+    ow = {r: list(obs_o.witnesses[r].items()) for r in obs_o.witnesses if obs_o.witnesses[r]}
+    assert rw == ow, "witnesses, dict order included"
+    in_table = {h for d in obs_r.witnesses.values() for h in d.values()}
+    assert {h: v for h, v in obs_r.famous.items() if h in in_table} == dict(obs_o.famous.items())
+    assert obs_r.consensus == obs_o.consensus and obs_r.tbd == obs_o.tbd
+    assert dict(obs_r.can_see[obs_r.head]) == dict(obs_o.can_see[obs_o.head])
+    assert obs_r.transactions == obs_o.transactions and (len(obs_r.transactions) > 0 or n == 3)
