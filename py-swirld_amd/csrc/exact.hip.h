@@ -76,6 +76,19 @@ struct Wave {
         return v;
     }
 };
+#elif defined(SW_EXACT_HOST_LANES)
+// CPU emulation of the wavefront for the tests (tests/exact_host.cpp): SW_EXACT_HOST_LANES cooperative
+// fibers, each running to its next sync() before the next one starts — the opposite extreme of the
+// lockstep execution of a real wavefront, so results that match under both need nothing but the syncs.
+extern "C" int swx_emul_lane();
+extern "C" void swx_emul_sync();
+extern "C" unsigned long long swx_emul_sum(unsigned long long v);
+struct Wave {
+    static int lane() { return swx_emul_lane(); }
+    static constexpr int nl = SW_EXACT_HOST_LANES;
+    static void sync() { swx_emul_sync(); }
+    static u64 sum(u64 v) { return swx_emul_sum(v); }
+};
 #else
 struct Wave {
     static int lane() { return 0; }

@@ -5,8 +5,66 @@
 #include "../py-swirld_amd/csrc/exact.hip.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
+
+// ---- run(body): the body once (one lane), or — built with -DSW_EXACT_HOST_LANES=64 — once per lane on
+// cooperative fibers that hand over at every sync(): lane 0 runs to its first sync, then lane 1, ...;
+// uniform control flow makes "yield to the next lane" a barrier.  A lane that ends while another
+// still waits in a sync is a non-uniform sync count: reported and aborted.
+#ifdef SW_EXACT_HOST_LANES
+#include <ucontext.h>
+namespace emul {
+constexpr int NL = SW_EXACT_HOST_LANES;
+ucontext_t main_ctx, ctx[NL];
+std::vector<char> stacks;
+bool done[NL];
+int cur = 0, syncs[NL];
+unsigned long long slot[NL];
+const std::function<void()>* body = nullptr;
+void entry() { (*body)(); done[cur] = true; swapcontext(&ctx[cur], &main_ctx); }
+void run(const std::function<void()>& f) {
+    body = &f;
+    if (stacks.empty()) stacks.resize((size_t)NL * (256 << 10));
+    for (int i = 0; i < NL; ++i) {
+        getcontext(&ctx[i]);
+        ctx[i].uc_stack.ss_sp = stacks.data() + (size_t)i * (256 << 10);
+        ctx[i].uc_stack.ss_size = 256 << 10;
+        ctx[i].uc_link = &main_ctx;
+        makecontext(&ctx[i], entry, 0);
+        done[i] = false; syncs[i] = 0;
+    }
+    for (;;) {  // one sweep = every live lane runs to its next sync (or to its end)
+        int live = 0;
+        for (int i = 0; i < NL; ++i) {
+            if (done[i]) continue;
+            cur = i;
+            swapcontext(&main_ctx, &ctx[i]);
+            live += !done[i];
+        }
+        if (!live) break;
+        for (int i = 0; i < NL; ++i)
+            if (done[i] != done[0] || syncs[i] != syncs[0]) { fprintf(stderr, "lanes disagree on the number of syncs (lane %d)\n", i); abort(); }
+    }
+}
+}  // namespace emul
+extern "C" int swx_emul_lane() { return emul::cur; }
+extern "C" void swx_emul_sync() { emul::syncs[emul::cur]++; swapcontext(&emul::ctx[emul::cur], &emul::main_ctx); }
+extern "C" unsigned long long swx_emul_sum(unsigned long long v) {
+    emul::slot[emul::cur] = v;
+    swx_emul_sync();
+    unsigned long long t = 0;
+    for (int i = 0; i < emul::NL; ++i) t += emul::slot[i];
+    swx_emul_sync();
+    return t;
+}
+static void run(const std::function<void()>& f) { emul::run(f); }
+#else
+static void run(const std::function<void()>& f) { f(); }
+#endif
 
 namespace {
 struct Ctx {
@@ -67,7 +125,10 @@ int swx_host_append(void* p, long long K, const int* cr, const int* sp, const in
 int swx_host_divide(void* p, long long first, long long K) {
     Ctx* c = (Ctx*)p;
     c->hdr[swx::H_RC] = 0;
-    return swx::divide(c->state(), first, K);
+    int rc = 0;
+    const swx::State st = c->state();
+    run([&] { const int r = swx::divide(st, first, K); if (r) rc = r; });
+    return rc;
 }
 int swx_host_fame(void* p, int* new_rounds, int* n_new) {
     Ctx* c = (Ctx*)p;
@@ -82,7 +143,9 @@ int swx_host_fame(void* p, int* new_rounds, int* n_new) {
     std::vector<unsigned char> s_m(c->np), done(c->Rcap);
     std::vector<int> nr(c->Rcap);
     x.votes = votes.data(); x.s_m = s_m.data(); x.done = done.data(); x.new_rounds = nr.data();
-    const int rc = swx::decide_fame(c->state(), x);
+    int rc = 0;
+    const swx::State st = c->state();
+    run([&] { const int r = swx::decide_fame(st, x); if (r) rc = r; });
     *n_new = (int)c->hdr[swx::H_NNEW];
     for (int i = 0; i < *n_new; ++i) new_rounds[i] = nr[i];
     return rc;
@@ -98,7 +161,9 @@ int swx_host_order(void* p, const int* rounds, int n_rounds, int* out, long long
     std::vector<double> times(c->np), tsort(c->np), items_ts(c->N + 1);
     x.queue = queue.data(); x.visited = visited.data(); x.fw = fw.data(); x.sflag = sflag.data(); x.times = times.data();
     x.tsort = tsort.data(); x.white = white.data(); x.items_ev = items_ev.data(); x.items_ts = items_ts.data();
-    const int rc = swx::find_order(c->state(), x, rs.data(), n_rounds);
+    int rc = 0;
+    const swx::State st = c->state();
+    run([&] { const int r = swx::find_order(st, x, rs.data(), n_rounds); if (r) rc = r; });
     *n_out = c->hdr[swx::H_NOUT];
     for (long long i = 0; i < *n_out; ++i) { out[i] = items_ev[i]; c->tx.push_back(items_ev[i]); }
     return rc;
@@ -125,6 +190,7 @@ void swx_host_import_check(void* p) {
     std::vector<int> worder0(c->worder), wcnt0(c->wcnt);
     std::vector<signed char> fam0(c->fam_ev);
     std::vector<unsigned char> tbd0(c->tbd);
-    swx::import_fast_state(c->state(), c->N, c->tx.data(), (long long)c->tx.size());
+    const swx::State st = c->state();
+    run([&] { swx::import_fast_state(st, c->N, c->tx.data(), (long long)c->tx.size()); });
 }
 }

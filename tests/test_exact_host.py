@@ -2,7 +2,11 @@
 divide / decide_fame / find_order, the reference's statements on the device-resident layout), compiled
 for the HOST by g++ (tests/exact_host.cpp, one "lane") and run against every golden fixture of the
 unmodified reference — the forked DAG included — and against the oracle on random forked hashgraphs,
-batch and incremental schedules.  The GPU run of the same cases is tests/test_gpu_forks.py."""
+batch and incremental schedules.  Two host builds: one "lane" (the plain sequential statement), and 16
+cooperative fibers that hand over at every sync — the opposite extreme of a wavefront's lockstep
+execution — so that the lane-parallel structure the kernels really run (lane-owned columns, wave
+sums, lane-0 sections) is exercised on the CPU and needs nothing but its syncs to be right.
+The GPU run of the same cases is tests/test_gpu_forks.py."""
 import ctypes as C
 import os
 import subprocess
@@ -16,14 +20,16 @@ from synth_util import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libswx_host.so")
+SO_LANES = os.path.join(HERE, "libswx_host_lanes.so")
 SRC = os.path.join(HERE, "exact_host.cpp")
 HDR = os.path.join(ROOT, "py-swirld_amd", "csrc", "exact.hip.h")
 
 
-def build_host_lib():
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", SO])
-    return SO
+def build_host_lib(lanes=False):
+    so, extra = (SO_LANES, ["-DSW_EXACT_HOST_LANES=16"]) if lanes else (SO, [])
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC"] + extra + [SRC, "-o", so])
+    return so
 
 
 def _p(a):
@@ -33,8 +39,8 @@ def _p(a):
 class ExactHost:
     """Oracle-like driver over the host build of exact.hip.h."""
 
-    def __init__(self, n, stake=None, coin_period=6):
-        L = C.CDLL(build_host_lib())
+    def __init__(self, n, stake=None, coin_period=6, lanes=False):
+        L = C.CDLL(build_host_lib(lanes))
         L.swx_host_create.restype = C.c_void_p
         L.swx_host_create.argtypes = [C.c_int, C.c_void_p, C.c_int]
         L.swx_host_destroy.argtypes = [C.c_void_p]
@@ -135,10 +141,10 @@ def add_forks(stream, n, seed, n_forks, start=0):
             np.array(out[3], np.float64), np.array(out[4], np.uint8).reshape(-1, 64))
 
 
-def run_both(n, stream, chunk, stake=None, with_order=True):
+def run_both(n, stream, chunk, stake=None, with_order=True, lanes=False):
     cr, sp, op, t, sig = stream
     N = len(cr)
-    o, x = Oracle(n, stake), ExactHost(n, stake)
+    o, x = Oracle(n, stake), ExactHost(n, stake, lanes=lanes)
     chunk = chunk or N
     for a in range(0, N, chunk):
         b = min(N, a + chunk)
@@ -170,10 +176,16 @@ def _small_goldens():  # (the large fixtures are the fast path's business; this 
     return [name for name in golden_names() if len(load_golden(name)["creator"]) <= 4000]
 
 
-@pytest.mark.parametrize("name", _small_goldens())
-def test_exact_path_matches_reference_golden(name):
+def _golden_cases():  # (a fiber switch per lane and sync: the many-call schedules stay with the 1-lane build)
+    return [pytest.param(name, lanes, id="%s-%s" % (name, "16lanes" if lanes else "1lane"))
+            for name in _small_goldens() for lanes in (False, True)
+            if not (lanes and len(load_golden(name)["batches"]) > 60)]
+
+
+@pytest.mark.parametrize("name,lanes", _golden_cases())
+def test_exact_path_matches_reference_golden(name, lanes):
     g = load_golden(name)
-    x = ExactHost(g["n"], g["stake"])
+    x = ExactHost(g["n"], g["stake"], lanes=lanes)
     calls = 0
     for a, b in g["batches"]:
         x.append_events(g["creator"][a:b], g["self_parent"][a:b], g["other_parent"][a:b], g["t"][a:b], g["sig"][a:b])
@@ -194,31 +206,38 @@ def test_exact_path_matches_reference_golden(name):
     assert np.array_equal(st["tbd"], g["tbd"])
 
 
-@pytest.mark.parametrize("n,N,seed,forks,chunk,mode,p0,p1", [
+FORK_CASES = [
     (8, 600, 1, 10, None, 0, 0, 0), (8, 600, 2, 10, 37, 0, 0, 0), (5, 400, 3, 25, 1, 0, 0, 0),
     (16, 1500, 4, 30, 100, 2, 0.3, 0.1), (70, 5000, 5, 12, 1000, 0, 0, 0), (4, 900, 6, 40, 9, 0, 0, 0),
     (12, 1000, 7, 20, None, 1, 0.02, 0),
-])
-def test_exact_path_matches_oracle_on_forked_hashgraphs(n, N, seed, forks, chunk, mode, p0, p1):
+]
+
+
+@pytest.mark.parametrize("n,N,seed,forks,chunk,mode,p0,p1,lanes",
+                         [c + (lanes,) for c in FORK_CASES for lanes in (False, True)
+                          if not (lanes and c[4] is not None and c[4] < 30)])
+def test_exact_path_matches_oracle_on_forked_hashgraphs(n, N, seed, forks, chunk, mode, p0, p1, lanes):
     stream = add_forks(synth(n, N, seed, mode, p0, p1), n, seed, forks)
-    o, x = run_both(n, stream, chunk)
+    o, x = run_both(n, stream, chunk, lanes=lanes)
     assert_same(o, x)
     assert o.max_round >= 3
 
 
-def test_exact_path_with_stake():
+@pytest.mark.parametrize("lanes", [False, True], ids=["1lane", "16lanes"])
+def test_exact_path_with_stake(lanes):
     n = 9
     stake = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9], np.uint64)
     stream = add_forks(synth(n, 800, 21), n, 21, 15)
-    o, x = run_both(n, stream, 60, stake)
+    o, x = run_both(n, stream, 60, stake, lanes=lanes)
     assert_same(o, x)
 
 
-def test_import_of_a_fork_free_state_rebuilds_order_fame_and_tbd():
+@pytest.mark.parametrize("lanes", [False, True], ids=["1lane", "16lanes"])
+def test_import_of_a_fork_free_state_rebuilds_order_fame_and_tbd(lanes):
     """What a context that ran on the fast path hands over at its first fork: per-slot tables only."""
     n = 10
     stream = synth(n, 900, 33)
-    o, x = run_both(n, stream, 45)
+    o, x = run_both(n, stream, 45, lanes=lanes)
     before = x.state()
     x.reimport()
     after = x.state()
