@@ -130,6 +130,9 @@ int sw_max_round(sw_ctx* ctx, int* out);                                        
 int sw_get_witnesses(sw_ctx* ctx, int r0, int r1, int32_t* out);
 /* Node.famous for the same table: -1 undecided, 0 False, 1 True (swirld.py:263). */
 int sw_get_famous(sw_ctx* ctx, int r0, int r1, int8_t* out);
+/* Node.famous keyed by event (swirld.py:64) for the events [first, first+K): -1 = undecided or not a
+ * witness, else 0 / 1.  Differs from the slot view only with forks (a replaced witness keeps its entry). */
+int sw_get_famous_events(sw_ctx* ctx, int64_t first, int64_t K, int8_t* out);
 /* Node.consensus membership for r in [r0, r1): 1 if r in consensus (swirld.py:276). */
 int sw_get_consensus(sw_ctx* ctx, int r0, int r1, uint8_t* out);
 /* Diagnostic: per event the member bitmask {c_ : round[can_see[e][c_]] == round[e]}

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sw_max_round": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "sw_get_witnesses": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "sw_get_famous": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "sw_get_famous_events": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_consensus": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "sw_get_sees_mask": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_vote": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int8)]),

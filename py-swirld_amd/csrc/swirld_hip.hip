@@ -2553,6 +2553,32 @@ int sw_get_famous(sw_ctx* c, int r0, int r1, int8_t* out) {
     return get_round_rows<signed char>(c, c ? c->d_fam.p : nullptr, r0, r1, (signed char*)out, (signed char)-1);
 }
 
+// Node.famous keyed by EVENT (swirld.py:64): -1 undecided / not a witness, 0 / 1.  On the fast path a
+// member has one witness per round for good, so this is the slot table scattered to the events; on the
+// exact path a fork sibling may have replaced a decided witness, whose entry the reference keeps.
+int sw_get_famous_events(sw_ctx* c, int64_t first, int64_t K, int8_t* out) {
+    if (!c || !out) return SW_EINVAL;
+    if (first < 0 || K < 0 || first + K > c->N) return fail(c, SW_ERANGE, "range outside the stored events");
+    if (!K) return SW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->exact) {
+        HIPCHK(c, hipMemcpyAsync(out, c->x_fam_ev.p + first, (size_t)K, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return SW_OK;
+    }
+    memset(out, 0xff, (size_t)K);
+    const int np = c->npad, R = c->R;
+    if (R <= 0) return SW_OK;
+    std::vector<int32_t> wit((size_t)R * np);
+    std::vector<signed char> fam((size_t)R * np);
+    HIPCHK(c, hipMemcpyAsync(wit.data(), c->d_wit.p, wit.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fam.data(), c->d_fam.p, fam.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < wit.size(); ++i)
+        if (wit[i] >= first && wit[i] < first + K) out[wit[i] - first] = fam[i];
+    return SW_OK;
+}
+
 int sw_get_consensus(sw_ctx* c, int r0, int r1, uint8_t* out) {
     if (!c || !out) return SW_EINVAL;
     if (r0 < 0 || r1 < r0) return fail(c, SW_ERANGE, "bad round range");

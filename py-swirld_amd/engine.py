@@ -162,6 +162,13 @@ class Hashgraph:
         self._chk(self._L.sw_get_famous(self._h, r0, r1, _p(out)))
         return out
 
+    def famous_events(self, first=0, K=None):
+        """Node.famous keyed by event: -1 undecided / not a witness, 0 / 1 (swirld.py:64)."""
+        K = self.num_events - first if K is None else K
+        out = np.empty(max(K, 0), np.int8)
+        self._chk(self._L.sw_get_famous_events(self._h, first, K, _p(out)))
+        return out
+
     def consensus(self, r0=0, r1=None):
         r1 = self.max_round + 1 if r1 is None else r1
         out = np.empty(max(r1 - r0, 0), np.uint8)

@@ -480,6 +480,10 @@ class Node:
         return self._wit_cache
 
     def _famous_dict(self):
+        if self._fam_cache is None and self._dev.exact:
+            # forks: a replaced witness keeps its entry (swirld.py:64 is keyed by event), so the per-event view
+            fe = self._dev.famous_events(0, self._divided)
+            self._fam_cache = {self._ids[int(e)]: bool(fe[e]) for e in np.flatnonzero(fe >= 0)}
         if self._fam_cache is None:
             wit, fam = self._witness_table(), self._dev.famous()
             d = {}

@@ -60,6 +60,10 @@ class OracleHashgraph:
     def famous(self, r0=0, r1=None):
         return self._o.famous_table(r0, r1)
 
+    def famous_events(self, first=0, K=None):
+        f = self._o.famous_by_event
+        return f[first:] if K is None else f[first:first + K]
+
     def known_heights(self, head_event):
         row = self._o.can_see[head_event]
         ht = self._o.height

@@ -230,8 +230,7 @@ def test_forked_hashgraph_matches_reference_node(pkg, monkeypatch, n, steps, see
     rw = {r: list(d.items()) for r, d in obs_r.witnesses.items() if d}
     ow = {r: list(obs_o.witnesses[r].items()) for r in obs_o.witnesses if obs_o.witnesses[r]}
     assert rw == ow, "witnesses, dict order included"
-    in_table = {h for d in obs_r.witnesses.values() for h in d.values()}
-    assert {h: v for h, v in obs_r.famous.items() if h in in_table} == dict(obs_o.famous.items())
+    assert dict(obs_r.famous.items()) == dict(obs_o.famous.items()), "fame per event, replaced witnesses included"
     assert obs_r.consensus == obs_o.consensus and obs_r.tbd == obs_o.tbd
     assert dict(obs_r.can_see[obs_r.head]) == dict(obs_o.can_see[obs_o.head])
     assert obs_r.transactions == obs_o.transactions and (len(obs_r.transactions) > 0 or n == 3)
