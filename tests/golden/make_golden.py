@@ -203,7 +203,7 @@ def main():
     print("%-28s N=%d R=%3d consensus=%3d tx=%5d calls=%d" % (
         "n4_mainloop_node0", len(out["creator"]), out["witnesses"].shape[0], int(out["consensus"].sum()),
         len(out["transactions"]), len(out["sched"])))
-    # forked DAG (oracle-only parity: the bulk HIP path refuses forks)
+    # forked DAG, batch (forks appended at the end of the stream)
     base = synth(8, 500, 11, 0, 0, 0)
     stream = add_forks(base, 8, 11, 6)
     out = run_case(8, stream, None, None)
@@ -211,7 +211,30 @@ def main():
     np.savez_compressed(path, **out)
     print("%-28s R=%3d consensus=%3d tx=%5d" % ("n8_s11_forks", out["witnesses"].shape[0],
                                                int(out["consensus"].sum()), len(out["transactions"])))
+    main_forks_incremental()
+
+
+# forked DAGs under INCREMENTAL call schedules: forks spread over the whole stream (the generator of
+# tests/test_exact_host.py), so that siblings replace witnesses between decide_fame() calls
+FORK_CASES = [
+    ("n8_s12_forks_chunk9", 8, 600, 12, 10, None, 9),
+    ("n5_s13_forks_chunk1", 5, 300, 13, 12, None, 1),
+    ("n12_s14_forks_stake_chunk40", 12, 1200, 14, 16, [1, 2, 1, 1, 3, 1, 1, 2, 1, 1, 1, 2], 40),
+]
+
+
+def main_forks_incremental():
+    from test_exact_host import add_forks as add_forks_spread
+    for name, n, N, seed, forks, stake, chunk in FORK_CASES:
+        stream = add_forks_spread(synth(n, N, seed, 0, 0, 0), n, seed, forks)
+        out = run_case(n, stream, stake, chunk)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("%-28s R=%3d consensus=%3d tx=%5d calls=%d" % (name, out["witnesses"].shape[0], int(out["consensus"].sum()),
+                                                            len(out["transactions"]), len(out["new_c_off"]) - 1))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--forks-incremental":   # only the fixtures added last
+        main_forks_incremental()
+    else:
+        main()
