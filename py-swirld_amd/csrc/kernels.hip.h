@@ -855,6 +855,169 @@ k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_star
     }
 }
 
+// EXPERIMENT (SW_FLOW_CFG=10, off by default; profiles/NOTES_next_round.md): the same dataflow sweep with
+// COLS columns per workgroup — COLS x npad worker lanes, still ONE loader wave and ONE descriptor FIFO
+// per member (descriptors do not depend on the column; a FIFO slot is free once the workers of every
+// column have taken it), one ring per column.  npad / COLS workgroups instead of npad: half of the CUs
+// carry no polling waves while the round loop runs next to the sweep, and the loader traffic halves.
+// MPL = 1 (n <= 256).  Same protocol and the same safety argument as k_cansee_flow.
+template <int NW, int COLS, int F, int H, bool WIDE>
+__global__ void __launch_bounds__(COLS * 64 * NW + 64)
+k_cansee_flow_cols(const int4* __restrict__ cdesc, const int* __restrict__ chain_start,
+                   const int* __restrict__ pos0, const int* __restrict__ pos1,
+                   const int* __restrict__ chain_ev, int first_event, int* L, int* err) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr int npad = 64 * NW;
+    constexpr int NT = COLS * npad;      // worker lanes
+    constexpr int SPIN_LIMIT = 1 << 27;
+    constexpr int hm = H - 1, fm = F - 1;
+    static_assert((H & hm) == 0 && (F & fm) == 0 && H <= 64 && H >= 8, "ring / FIFO depths are powers of two; H > 6 store instructions");
+    static_assert(npad % (8 * COLS) == 0, "columns per XCD");
+    int4* fifo = (int4*)smem;                                  // [F][npad], shared by the columns
+    u64* ring = (u64*)(fifo + (size_t)F * npad);               // [COLS][H][npad] {value << 32 | event id}
+    int* filled = (int*)(ring + (size_t)COLS * H * npad);      // [npad]
+    int* taken = filled + npad;                                // [COLS][npad]
+    const int tid = threadIdx.x;
+    const bool loader = tid >= NT;
+    const int ll = tid - NT;
+    const int nblk = gridDim.x;                                // npad / COLS
+    // workgroup b runs on XCD b % 8: each XCD keeps npad / 8 consecutive columns (whole lines of a row in its L2)
+    const int col0 = (nblk % 8 == 0) ? (blockIdx.x % 8) * (npad / 8) + (blockIdx.x / 8) * COLS : blockIdx.x * COLS;
+    for (int i = tid; i < COLS * npad * H; i += blockDim.x) ring[i] = 0xffffffffffffffffull;
+    for (int i = tid; i < npad; i += blockDim.x) {
+        const int p = pos0[i];
+        filled[i] = p;
+#pragma unroll
+        for (int s_ = 0; s_ < COLS; ++s_) taken[s_ * npad + i] = p;
+    }
+    __syncthreads();
+    if (loader) {
+        constexpr int B = F / 2;
+        constexpr int MAXBUF = 32;
+        constexpr int G = (NW * B <= MAXBUF) ? NW : MAXBUF / B;
+        static_assert(G >= 1 && NW % G == 0, "loader groups");
+        int fl[NW], pe[NW], cs[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int k = ll + 64 * j;
+            fl[j] = pos0[k];
+            pe[j] = pos1[k];
+            cs[j] = chain_start[k];
+        }
+        for (int spins = 0;; ++spins) {
+            bool more = false;
+            unsigned need = 0;
+            if (spins > SPIN_LIMIT) { if (ll == 0) atomicExch(err, 2); break; }
+            SW_CBAR();
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                if (fl[j] < pe[j]) {
+                    more = true;
+                    int tk = taken[ll + 64 * j];
+#pragma unroll
+                    for (int s_ = 1; s_ < COLS; ++s_) { const int t2 = taken[s_ * npad + ll + 64 * j]; tk = t2 < tk ? t2 : tk; }
+                    if (fl[j] - tk <= F - B) need |= 1u << j;
+                }
+            }
+            if (!__ballot(more)) break;
+            if (!__ballot(need != 0)) { __builtin_amdgcn_s_sleep(2); continue; }
+#pragma unroll
+            for (int g0 = 0; g0 < NW; g0 += G) {
+                int bx[G * B], by[G * B], bz[G * B];
+#pragma unroll
+                for (int jj = 0; jj < G; ++jj) {
+                    const int j = g0 + jj;
+                    const int last = pe[j] > 0 ? pe[j] - 1 : 0;
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        const int pos = fl[j] + u < pe[j] ? fl[j] + u : last;
+                        const int4 t = cdesc[(size_t)cs[j] + pos];
+                        bx[jj * B + u] = t.x; by[jj * B + u] = t.y; bz[jj * B + u] = t.z;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < G; ++jj) {
+                    const int j = g0 + jj;
+                    if ((need >> j) & 1u) {
+                        const int k = ll + 64 * j;
+                        int nf = fl[j];
+#pragma unroll
+                        for (int u = 0; u < B; ++u)
+                            if (fl[j] + u < pe[j]) {
+                                fifo[(size_t)((fl[j] + u) & fm) * npad + k] = make_int4(bx[jj * B + u], by[jj * B + u], bz[jj * B + u], 0);
+                                nf = fl[j] + u + 1;
+                            }
+                        SW_CBAR();
+                        filled[k] = nf;
+                        SW_CBAR();
+                        fl[j] = nf;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- workers: lane = (column s, member m)
+    const int s = tid / npad, m = tid - s * npad;
+    const int col = col0 + s;
+    u64* const myring = ring + (size_t)s * H * npad;
+    int* const mytaken = taken + s * npad;
+    char* const Lcol = reinterpret_cast<char*>(L + col);
+    int p = pos0[m];
+    const int pend = pos1[m];
+    int mine = -1, ev = -1, opar = -1, ridx = 0;
+    bool have = false;
+    if (p > 0 && p < pend) {
+        const int prev = chain_ev[chain_start[m] + p - 1];
+        mine = L[(size_t)prev * npad + col];
+    }
+    asm volatile("" : "+v"(mine));
+    for (int spins = 0;; ++spins) {
+        if (spins > SPIN_LIMIT) { if ((tid & 63) == 0) atomicExch(err, 1); break; }
+        SW_CBAR();
+        const u64 pr = myring[ridx];
+        const int fcnt = filled[m];
+        SW_CBAR();
+        const int4 nd = fifo[((p + (have ? 1 : 0)) & fm) * npad + m];
+        SW_CBAR();
+        const int o = opar;
+        const int tag = (int)(unsigned)pr;
+        const bool hit = tag == o;
+        int other = hit ? (int)(pr >> 32) : -1;
+        bool ready = have && (o < 0 || hit);
+        const bool from_mem = have && o >= 0 && !hit && (o < first_event || tag > o);
+        if (__ballot(from_mem)) {
+            if (from_mem) {
+                other = load_sc1_and_wait(WIDE ? &L[(size_t)o * npad + col]
+                                               : reinterpret_cast<const int*>(Lcol + (unsigned)o * (unsigned)(npad * 4)));
+                ready = true;
+            }
+        }
+        if (ready) {
+            const int e = ev;
+            int v = mine > other ? mine : other;
+            if (col == m) v = e;
+            mine = v;
+            if (WIDE) L[(size_t)e * npad + col] = v;
+            else *reinterpret_cast<int*>(Lcol + (unsigned)e * (unsigned)(npad * 4)) = v;
+            myring[(p & hm) * npad + m] = ((u64)(unsigned)v << 32) | (unsigned)e;
+            ++p;
+            have = false;
+        }
+        if (!have && p < pend && p < fcnt) {  // nd is the descriptor of position p
+            ev = nd.x;
+            opar = nd.y;
+            ridx = ((nd.z >> 10) & hm) * npad + (nd.z & 1023);
+            have = true;
+            mytaken[m] = p + 1;
+        }
+        if constexpr (H >= 32) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        else if constexpr (H >= 16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!__ballot(p < pend)) break;
+    }
+}
+
 // chain positions of the sub-batch cuts: out[i][m] = number of member m's events with index < cut[i]
 __global__ void __launch_bounds__(1024)
 k_chain_bounds(const int* __restrict__ chain_start, const int* __restrict__ chain_cnt,

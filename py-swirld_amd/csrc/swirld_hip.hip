@@ -165,7 +165,7 @@ struct sw_ctx {
     int BATCH = 24;    // loop iterations between host checks
     int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers; k_cansee_flow); 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
-    int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
+    int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32; 10 = experiment, two columns per workgroup
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
     int band_blocks = 512; // workgroups of the resolve+band kernel
@@ -646,6 +646,33 @@ int launch_cansee_flow_t(sw_ctx* c, int i, int64_t first_event) {
     return SW_OK;
 }
 
+// EXPERIMENT (SW_FLOW_CFG=10): COLS columns per workgroup, npad / COLS workgroups (k_cansee_flow_cols)
+template <int NW, int COLS, int F, int H>
+int launch_cansee_flow_cols(sw_ctx* c, int i, int64_t first_event) {
+    constexpr int npad = 64 * NW;
+    const size_t lds = (size_t)npad * ((size_t)F * 16 + (size_t)COLS * H * 8 + 4 + (size_t)COLS * 4);
+    const bool wide = (size_t)c->cap * (size_t)npad * sizeof(int32_t) >= (1ull << 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_cansee_flow_cols<NW, COLS, F, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute((const void*)k_cansee_flow_cols<NW, COLS, F, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+        attr_set = true;
+    }
+    const int* p0 = (const int*)c->d_bounds.p + (size_t)i * npad;
+    const int* p1 = (const int*)c->d_bounds.p + (size_t)(i + 1) * npad;
+    if (wide)
+        hipLaunchKernelGGL((k_cansee_flow_cols<NW, COLS, F, H, true>), dim3(npad / COLS), dim3(COLS * npad + 64), lds, c->stream_cs,
+                           (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, p0, p1, (const int*)c->d_chain_ev.p,
+                           (int)first_event, c->d_L.p, c->d_flow_err);
+    else
+        hipLaunchKernelGGL((k_cansee_flow_cols<NW, COLS, F, H, false>), dim3(npad / COLS), dim3(COLS * npad + 64), lds, c->stream_cs,
+                           (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, p0, p1, (const int*)c->d_chain_ev.p,
+                           (int)first_event, c->d_L.p, c->d_flow_err);
+    c->ctr.kernel_launches++;
+    HIPCHK(c, hipGetLastError());
+    return SW_OK;
+}
+
 template <int NW, int MPL, int F, int H>
 int launch_cansee_flow_g(sw_ctx* c, int i, int64_t first_event) {
     // 32-bit row offsets while the can_see table stays below 4 GB
@@ -665,6 +692,7 @@ int launch_cansee_flow(sw_ctx* c, int i, int64_t first_event) {
             case 0: return launch_cansee_flow_g<NW, 1, 16, 32>(c, i, first_event);
             case 2: return launch_cansee_flow_g<NW, 1, 16, 16>(c, i, first_event);
             case 3: return launch_cansee_flow_g<NW, 1, 8, 32>(c, i, first_event);
+            case 10: return launch_cansee_flow_cols<NW, 2, 8, 16>(c, i, first_event);   // experiment: two columns per workgroup
             default: return launch_cansee_flow_g<NW, 1, 8, 16>(c, i, first_event);
         }
     }
