@@ -55,3 +55,50 @@ def test_random_streams(pkg, seed):
     assert np.array_equal(ex["consensus"], orc.consensus())
     assert np.array_equal(ex["transactions"], orc.transactions)
     assert len(ex["votes"]) == orc.num_votes
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_forked_streams(pkg, seed):
+    """The same comparison on FORKED hashgraphs (the reference stores forks, README.md:84): height-based
+    maxi with ties, witnesses replaced by fork siblings between calls, fame keyed by event, and — with
+    them — the exact path's host builds next to the oracle."""
+    from test_exact_host import ExactHost, add_forks
+    rng = np.random.default_rng(7000 + seed)
+    n, N, mode, p0, p1, stake, chunk = random_case(rng)
+    n, N = max(n, 3), max(N, 6 * n)
+    base = pkg.synth_hashgraph(n, N, 9000 + seed, mode, p0, p1)
+    cr, sp, op, t, sig = add_forks(base, n, seed, int(rng.integers(2, 30)))
+    N = len(cr)
+    ref, orc = RefRun(n, stake), Oracle(n, None if stake is None else stake.astype(np.uint64))
+    exh = ExactHost(n, None if stake is None else stake.astype(np.uint32), lanes=bool(seed % 2) and (chunk is None or chunk > 30))
+    chunk = chunk or N
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        ref.append(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+        ref.divide_rounds(a, b - a)
+        for d in (orc, exh):
+            d.append_events(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+            d.divide_rounds(a, b - a)
+        nc_ref = list(ref.decide_fame())
+        assert nc_ref == list((nc := orc.decide_fame())) == list(exh.decide_fame())
+        try:
+            tx_ref = ref.find_order(nc)
+        except IndexError:  # swirld.py:305
+            with pytest.raises(OracleError):
+                orc.find_order(nc)
+            with pytest.raises(IndexError):
+                exh.find_order(nc)
+            return
+        assert list(tx_ref) == list(orc.find_order(nc)) == list(exh.find_order(nc))
+    ex = ref.extract()
+    st = exh.state()
+    assert np.array_equal(ex["round"], orc.round) and np.array_equal(ex["round"], st["round"])
+    assert np.array_equal(ex["can_see"], orc.can_see) and np.array_equal(ex["can_see"], st["can_see"])
+    assert np.array_equal(ex["witnesses"], orc.witnesses()) and np.array_equal(ex["witnesses"], st["wit"])
+    for r, order in enumerate(ex["wit_order"]):
+        assert np.array_equal(order, orc.witness_order(r)) and np.array_equal(order, st["worder"][r])
+    assert np.array_equal(ex["famous"], orc.famous_by_event) and np.array_equal(ex["famous"], st["fam"])
+    assert np.array_equal(ex["consensus"], orc.consensus()) and np.array_equal(ex["consensus"], st["cons"])
+    assert np.array_equal(ex["transactions"], orc.transactions)
+    assert np.array_equal(ex["tbd"], orc.tbd) and np.array_equal(ex["tbd"], st["tbd"])
+    assert len(ex["votes"]) == orc.num_votes
