@@ -103,8 +103,9 @@ int sw_decide_fame(sw_ctx* ctx, int32_t* new_rounds, int cap, int* n_new);
  * owned) and decided[R] (1: every witness of the round is decided, swirld.py:274-275) — and commits
  * nothing.  The element-wise MAX of all parts' tables (one all-reduce; py-swirld_amd/partition.py)
  * given to sw_commit_fame on every part leaves each context exactly as sw_decide_fame() would:
- * same famous table, consensus set and new_c.  (Node.votes bookkeeping of rounds decided by
- * another part has no deciding voter recorded.)
+ * same famous table, consensus set and new_c — and nothing else: the deciding call / voter of a
+ * witness (what Node.votes' existence rule needs) is recorded only on the part that ran its
+ * election, so after a sw_commit_fame sw_get_vote returns SW_ENOTSUP until sw_reset / sw_rewind.
  */
 int sw_decide_fame_partial(sw_ctx* ctx, int part, int nparts, int8_t* famous, uint8_t* decided,
                            int r_cap, int* r_out);

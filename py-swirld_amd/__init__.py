@@ -9,7 +9,7 @@ with `importlib.import_module("py-swirld_amd")` or through the alias module
 """
 from ._lib import SwirldHipError, LIB_PATH  # noqa: F401
 from .engine import Hashgraph, hash_batch, synth_hashgraph, verify_batch  # noqa: F401
-from .node import C, Event, Node, majority, test  # noqa: F401
+from .node import C, Event, Node, VotesUnavailable, majority, test  # noqa: F401
 
 __all__ = ["Hashgraph", "synth_hashgraph", "verify_batch", "hash_batch", "SwirldHipError", "LIB_PATH",
-           "Node", "Event", "C", "majority", "test"]
+           "Node", "Event", "C", "majority", "test", "VotesUnavailable"]

@@ -124,6 +124,7 @@ struct sw_ctx {
     DBuf<int32_t> d_dec_call, d_dec_by;  // per witness slot: the decide_fame() call that decided it and the deciding voter (Node.votes bookkeeping)
     struct FameCall { int max_c, R; int64_t divided; };
     std::vector<FameCall> fame_calls;    // one record per decide_fame() call
+    bool votes_partial = false;          // a partitioned commit left dec_call / dec_by of other parts' witnesses unset: no Node.votes
     std::vector<int32_t> cons_call;      // per round: the call that added it to `consensus` (-1: not yet)
     DBuf<unsigned char> d_cons, d_newc;
     DBuf<u64> d_Sw;
@@ -2315,6 +2316,7 @@ int sw_commit_fame(sw_ctx* c, const int8_t* famous, const uint8_t* decided, int 
     std::vector<unsigned char> cons(R - max_c, 0);
     const int call_idx = (int)c->fame_calls.size();
     c->fame_calls.push_back({max_c, R, c->divided});
+    c->votes_partial = true;  // the deciding call / voter of witnesses decided by other parts is unknown here: sw_get_vote refuses
     int cnt = 0;
     for (int r = max_c; r < R; ++r) {
         for (int m = 0; m < n; ++m) fam[(size_t)(r - max_c) * np + m] = famous[(size_t)r * n + m];
@@ -2446,6 +2448,7 @@ int sw_rewind(sw_ctx* c) {
     CHK(fill_i32(c, c->d_dec_call.p, rows, -1));
     CHK(fill_i32(c, c->d_dec_by.p, rows, -1));
     c->fame_calls.clear();
+    c->votes_partial = false;
     std::fill(c->cons_call.begin(), c->cons_call.end(), -1);
     HIPCHK(c, hipMemsetAsync(c->d_fam.p, 0xff, rows, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cons.p, 0, c->Rcap, c->stream));
@@ -2647,6 +2650,7 @@ int sw_get_vote(sw_ctx* c, int rv, int mv, int rc, int mc, int8_t* out) {
     if (!c || !out) return SW_EINVAL;
     *out = -1;
     if (c->exact) return fail(c, SW_ENOTSUP, "sw_get_vote is not available on the exact (forked-hashgraph) path");
+    if (c->votes_partial) return fail(c, SW_ENOTSUP, "sw_get_vote is not available after sw_commit_fame (the deciding voters of other parts' witnesses are not recorded)");
     const int np = c->npad, nw = c->nw, n = c->n;
     if (rc < 0 || rv >= c->R || mv < 0 || mv >= n || mc < 0 || mc >= n) return fail(c, SW_ERANGE, "witness slot outside the table");
     if (rv <= rc) return SW_OK;

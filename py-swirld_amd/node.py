@@ -134,6 +134,13 @@ class _FamousView(Mapping):
         return len(self._dict())
 
 
+class VotesUnavailable(LookupError):
+    """Node.votes is not kept in this state: the context stored a forked event (the exact path keeps two
+    vote layers, not the history: sw_get_vote -> SW_ENOTSUP) or fame was committed from a partitioned
+    decide_fame (sw_commit_fame).  Deliberately NOT a KeyError: `votes.get(...)` / `in` must not read
+    "no such entry" where the answer is unknown.  round / witnesses / famous / consensus are unaffected."""
+
+
 class _VoterVotes(Mapping):
     """Node.votes[y]: {candidate witness hash -> bool} of one voter."""
 
@@ -181,12 +188,18 @@ class _VotesView(Mapping):
     def __init__(self, node):
         self._n = node
 
+    def _check(self):
+        if self._n._dev.exact:
+            raise VotesUnavailable("votes are not kept once a forked event was stored (exact path)")
+
     def __getitem__(self, y):
+        self._check()
         if y not in self._n._index:
             raise KeyError(y)
         return _VoterVotes(self._n, y)
 
     def __iter__(self):
+        self._check()
         nd = self._n
         wit = nd._witness_table()
         for r in range(1, wit.shape[0]):
@@ -210,12 +223,15 @@ class Node:
     # the host (one signature costs a GPU thread ~1-2 ms of latency, a CPU core ~60 us).  None = never.
     device_crypto_threshold = 512
 
-    def __init__(self, kp, network, n_nodes, stake, device=0, accept_forks=False):
+    def __init__(self, kp, network, n_nodes, stake, device=0, accept_forks=True):
         self.pk, self.sk = kp
         # Forked events (two events of a member on one self-parent; the reference stores them, README.md:84).
-        # False [default]: dropped in is_valid_event — an honest node keeps its round-synchronous device
-        # path.  True: stored as in the reference; the device context then moves to the exact path
-        # (csrc/exact.hip.h: identical results, one wavefront — a single Byzantine fork slows this node down).
+        # True [default]: stored as in the reference (swirld.py:104-112 has no fork detection); the device
+        # context then moves to the exact path (csrc/exact.hip.h: identical results, one wavefront — a
+        # Byzantine fork slows this node down, it does not stop it).  False: a forked event and everything
+        # built on it is dropped in is_valid_event, which keeps the round-synchronous device path but cuts
+        # this node off from every honest member that did accept the sibling (their later events have an
+        # ancestor this node refuses) — only for closed simulations without equivocation.
         self.accept_forks = bool(accept_forks)
         self.network = network  # {pk -> Node.ask_sync}
         self.n = n_nodes
@@ -238,7 +254,8 @@ class Node:
         self._mindex = {pk: i for i, pk in enumerate(self._members)}
         self._ids = []
         self._index = {}
-        self._chain_head = {}  # {member pk -> its newest event in this view} (fork rejection)
+        self._chain_head = {}  # {member pk -> its newest event in this view} (fork detection)
+        self._trunk_height = {}  # {member pk that forked -> height of its earliest forked self-parent (-1: second root)}
         self._chains = [[] for _ in range(n_nodes)]  # per member: its events in self-parent order (hashes)
         self._pending = []    # (creator, self_parent, other_parent, t, sig) not yet uploaded
         self._uploaded = 0
@@ -327,6 +344,10 @@ class Node:
     def add_event(self, h, ev):
         """Store an event (swirld.py:114-120); it is uploaded with the next divide_rounds."""
         self.hg[h] = ev
+        if ev.c in self._chain_head and self._chain_head[ev.c] != (ev.p[0] if ev.p else None):
+            # a fork of member ev.c: everything of it above the forked self-parent may be on a branch a peer lacks
+            th = self.height[ev.p[0]] if ev.p else -1
+            self._trunk_height[ev.c] = min(self._trunk_height.get(ev.c, th), th)
         self._chain_head[ev.c] = h
         self.tbd.add(h)
         self.height[h] = 1 + max(self.height[p] for p in ev.p) if ev.p else 0
@@ -354,22 +375,32 @@ class Node:
         unknown = remote_hg.keys() - self.hg.keys()
         new = tuple(toposort(unknown, lambda u: remote_hg[u].p))
         thr = self.device_crypto_threshold
+        if not crypto.HAVE_SODIUM:  # stand-in signatures are keyed hashes: the device verifier (real Ed25519) would refuse all of them
+            thr = None
         pre = self._batch_crypto(new, remote_hg) if thr is not None and len(new) >= thr else {}
+        # Only what was actually stored is returned (main() hands it to divide_rounds): the reference
+        # returns the rejected ids too and then fails on them (swirld.py:134-146, 326), and references an
+        # unbound `h` when the remote head itself is rejected; here a bad payload costs the step, not the node.
+        added = []
         for eid in new:
             if self.is_valid_event(eid, remote_hg[eid], pre.get(eid)):
                 self.add_event(eid, remote_hg[eid])
-        if self.is_valid_event(remote_head, remote_hg[remote_head]):
+                added.append(eid)
+        if remote_head in remote_hg and self.is_valid_event(remote_head, remote_hg[remote_head]):
             h, ev = self.new_event(payload, (self.head, remote_head))
             assert self.is_valid_event(h, ev)
             self.add_event(h, ev)
             self.head = h
-        return new + (h,)
+            added.append(h)
+        return tuple(added)
 
     def ask_sync(self, pk, info):
         """Answer a sync request with every event the asker cannot know yet: walk back from
         my head, not descending below what the asker reported per member (swirld.py:148-161)."""
         asker_heights = loads(crypto.sign_open(info, pk))
-        if self.device_sync_diff and self._index[self.head] < self._divided:
+        # (a context on the exact path — it has stored a fork — has no sw_sync_diff and `_chains` is no longer
+        # one chain per member: the BFS below serves it, so a peer cannot break ask_sync by delivering a fork)
+        if self.device_sync_diff and not self._dev.exact and self._index[self.head] < self._divided:
             known = np.full(self.n, -1, np.int32)
             for creator, hgt in asker_heights.items():
                 c = self._mindex.get(creator)
@@ -382,10 +413,21 @@ class Node:
                     subset[eid] = self.hg[eid]
             return crypto.sign(dumps((self.head, subset)), self.sk)
 
+        # EXTENSION of the reference's height-pruned diff (swirld.py:154-161), active only for members this
+        # node has seen fork: one reported height cannot tell which BRANCH the asker has (fork siblings
+        # can even have equal heights), so for such a member the walk is pruned at its trunk — the part
+        # below its earliest fork point, which every branch contains — instead of at the reported height.
+        # Without it two honest nodes holding different siblings can never exchange them, and each
+        # refuses everything the other builds afterwards (unknown parent).
+        trunk = self._trunk_height
+
         def missing_parents(u):
             for p in self.hg[u].p:
                 creator = self.hg[p].c
-                if creator not in asker_heights or self.height[p] > asker_heights[creator]:
+                known = asker_heights.get(creator)
+                if known is not None and creator in trunk:
+                    known = min(known, trunk[creator])
+                if known is None or self.height[p] > known:
                     yield p
 
         subset = {}

@@ -8,23 +8,18 @@ import ctypes as C
 import hashlib
 import os
 import random
-import subprocess
 
 import pytest
 
+import hostlibs
 from conftest import ROOT
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libswc_host.so")
-SRC = os.path.join(HERE, "crypto_host.cpp")
-HDR = os.path.join(ROOT, "py-swirld_amd", "csrc", "crypto.hip.h")
 L_ORDER = 2 ** 252 + 27742317777372353535851937790883648493
 
 
 def build_host_lib():
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", SO])
-    return SO
+    return hostlibs.build_crypto_host()
 
 
 def load_sodium():

@@ -9,27 +9,20 @@ sums, lane-0 sections) is exercised on the CPU and needs nothing but its syncs t
 The GPU run of the same cases is tests/test_gpu_forks.py."""
 import ctypes as C
 import os
-import subprocess
 
 import numpy as np
 import pytest
 
+import hostlibs
 from conftest import ROOT, golden_names, load_golden
 from oracle.oracle import Oracle
 from synth_util import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libswx_host.so")
-SO_LANES = os.path.join(HERE, "libswx_host_lanes.so")
-SRC = os.path.join(HERE, "exact_host.cpp")
-HDR = os.path.join(ROOT, "py-swirld_amd", "csrc", "exact.hip.h")
 
 
 def build_host_lib(lanes=False):
-    so, extra = (SO_LANES, ["-DSW_EXACT_HOST_LANES=16"]) if lanes else (SO, [])
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC"] + extra + [SRC, "-o", so])
-    return so
+    return hostlibs.build_exact_host(lanes)
 
 
 def _p(a):
