@@ -194,6 +194,10 @@ typedef struct sw_counters {
     int64_t band_events;         /* band events whose threshold mask was built by the round loop      */
     int64_t coin_votes;          /* votes cast in coin rounds, d % C == 0 (swirld.py:267-272)          */
     int64_t coin_flips;          /* ... of which taken from the voter's signature bit (swirld.py:272)  */
+    int64_t chunk_sweeps;        /* chunks of the can_see table swept concurrently (k_cansee_chunks)     */
+    int64_t chunk_provisional;   /* entries a chunk could not know (ancestor older than its halo)        */
+    int64_t chunk_repaired;      /* ... of which changed by the repair kernel                            */
+    int64_t chunk_resweeps;      /* chunks swept a second time from final rows (too many to repair)      */
 } sw_counters;
 int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 

@@ -44,6 +44,26 @@ struct FameCounters {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Wave and workgroup reductions for the resolve step.  LDS atomics on one address with a
+// different value per lane are expanded by the compiler into a 64-trip scalar loop (~2 us on the
+// critical path of every iteration): butterflies + one LDS slot per wave + ONE barrier instead.
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+
 // ---------------------------------------------------------------------------------
 // Level buckets: events of one divide_rounds batch sorted by DAG height, so that all
 // events of one level are independent (parents have strictly smaller height,
@@ -855,54 +875,119 @@ k_cansee_flow(const int4* __restrict__ cdesc, const int* __restrict__ chain_star
     }
 }
 
-// EXPERIMENT (SW_FLOW_CFG=10, off by default; profiles/NOTES_next_round.md): the same dataflow sweep with
-// COLS columns per workgroup — COLS x npad worker lanes, still ONE loader wave and ONE descriptor FIFO
-// per member (descriptors do not depend on the column; a FIFO slot is free once the workers of every
-// column have taken it), one ring per column.  npad / COLS workgroups instead of npad: half of the CUs
-// carry no polling waves while the round loop runs next to the sweep, and the loader traffic halves.
-// MPL = 1 (n <= 256).  Same protocol and the same safety argument as k_cansee_flow.
-template <int NW, int COLS, int F, int H, bool WIDE>
-__global__ void __launch_bounds__(COLS * 64 * NW + 64)
-k_cansee_flow_cols(const int4* __restrict__ cdesc, const int* __restrict__ chain_start,
-                   const int* __restrict__ pos0, const int* __restrict__ pos1,
-                   const int* __restrict__ chain_ev, int first_event, int* L, int* err) {
+// ---------------------------------------------------------------------------------
+// Seventh version: CHUNK-PARALLEL dataflow sweep (tests/model_chunks.py is its executable statement).
+//
+// The dataflow sweep above is bound by the DEPTH of the hashgraph: one dependent LDS hop per DAG
+// level (~0.4 us), 13.2 k levels per million events at 256 members, whatever the number of
+// columns.  Here the events of one launch [a_0, a_G) are cut into G chunks that are swept
+// CONCURRENTLY, chunk k from w_k = max(a_0, a_k - halo) on; a parent in [a_0, w_k) — a row another
+// chunk is computing right now — is treated as a LEAF (the row {creator(x): x}).  A computed value
+// >= w_k is final (an in-window ancestor by that member exists and every path to it stays inside
+// the window); a smaller one is PROVISIONAL, counted, and repaired afterwards by k_cansee_fixup —
+// or, when a chunk has too many of them (members silent for longer than the halo), the chunk is
+// swept again from final rows (the same kernel, `exact_chunk` >= 0, gated on the count).  At uniform
+// gossip the oldest entry of a row is ~13.4 n events old (max 6.4 k at 256 members), so a halo of
+// 32 n events leaves nothing to repair and the sweep is G times shallower.
+//   * C columns per LANE: the dependency structure (which event waits for which) is the same for
+//     every column, so one poll / one descriptor / one 4C-byte store serve C columns, and a launch
+//     needs npad / C workgroups per chunk: G = C chunks occupy the chip exactly like one unchunked
+//     sweep did.  Ring entries are {value, tag} pairs, two per 16-byte plane; every tag is checked.
+//   * Halo rows [w_k, a_k) are recomputed for the dataflow only and go to a scratch table (chunk
+//     k-1 stores the real ones), which is also what a reused ring slot is re-read from.
+//   * Same protocol and the same safety argument as k_cansee_flow (one store instruction per
+//     completed event, at most H - 4 in flight per wave); MPL = 1 (n <= 256).
+// ---------------------------------------------------------------------------------
+#define SW_MAX_CHUNKS 8
+struct ChunkEv {
+    int w[SW_MAX_CHUNKS];  // window start of chunk k (first recomputed event)
+    int a[SW_MAX_CHUNKS];  // first event whose row chunk k stores
+};
+
+template <int C> struct ColVec;
+template <> struct ColVec<2> { typedef int2 T; };
+template <> struct ColVec<4> { typedef int4 T; };
+
+template <int C>
+__device__ __forceinline__ void load_cols_sc1_and_wait(const int* ptr, int (&v)[C]) {
+    if constexpr (C == 4) {
+        int4 t;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(ptr) : "memory");
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        int2 t;
+        asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(ptr) : "memory");
+        v[0] = t.x; v[1] = t.y;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_cols(int* ptr, const int (&v)[C]) {
+    if constexpr (C == 4) *reinterpret_cast<int4*>(ptr) = make_int4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<int2*>(ptr) = make_int2(v[0], v[1]);
+}
+
+template <int NW, int C, int F, int H, bool WIDE>
+__global__ void __launch_bounds__(64 * NW + 64)
+k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_start, const int* __restrict__ chain_ev,
+                const int* __restrict__ bnd, ChunkEv ce, int a0_all, int exact_chunk, int n_members,
+                int* L, int* halo, int halo_cap, unsigned* prov, unsigned gate_limit, int* err) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int npad = 64 * NW;
-    constexpr int NT = COLS * npad;      // worker lanes
+    constexpr int NT = npad;             // worker lanes = members
+    constexpr int NCG = npad / C;        // column groups = workgroups per chunk
+    constexpr int PL = C / 2;            // 16-byte ring planes: two {value, tag} pairs each
     constexpr int SPIN_LIMIT = 1 << 27;
     constexpr int hm = H - 1, fm = F - 1;
+    static_assert(C == 2 || C == 4, "columns per lane");
     static_assert((H & hm) == 0 && (F & fm) == 0 && H <= 64 && H >= 8, "ring / FIFO depths are powers of two; H > 6 store instructions");
-    static_assert(npad % (8 * COLS) == 0, "columns per XCD");
-    int4* fifo = (int4*)smem;                                  // [F][npad], shared by the columns
-    u64* ring = (u64*)(fifo + (size_t)F * npad);               // [COLS][H][npad] {value << 32 | event id}
-    int* filled = (int*)(ring + (size_t)COLS * H * npad);      // [npad]
-    int* taken = filled + npad;                                // [COLS][npad]
+    int4* fifo = (int4*)smem;                                  // [F][npad]
+    int4* ring = fifo + (size_t)F * npad;                      // [PL][H][npad] {v, tag, v', tag}
+    int* filled = (int*)(ring + (size_t)PL * H * npad);        // [npad]
+    int* taken = filled + npad;                                // [npad]
     const int tid = threadIdx.x;
     const bool loader = tid >= NT;
     const int ll = tid - NT;
-    const int nblk = gridDim.x;                                // npad / COLS
-    // workgroup b runs on XCD b % 8: each XCD keeps npad / 8 consecutive columns (whole lines of a row in its L2)
-    const int col0 = (nblk % 8 == 0) ? (blockIdx.x % 8) * (npad / 8) + (blockIdx.x / 8) * COLS : blockIdx.x * COLS;
-    for (int i = tid; i < COLS * npad * H; i += blockDim.x) ring[i] = 0xffffffffffffffffull;
-    for (int i = tid; i < npad; i += blockDim.x) {
-        const int p = pos0[i];
-        filled[i] = p;
-#pragma unroll
-        for (int s_ = 0; s_ < COLS; ++s_) taken[s_ * npad + i] = p;
+    // workgroup b runs on XCD b % 8 (observed, used for locality only): each XCD keeps NCG / 8 consecutive
+    // column groups = npad / 8 consecutive columns of every chunk, i.e. whole 128-byte lines of a row
+    int k, cg;
+    if (exact_chunk >= 0) {
+        k = exact_chunk;
+        cg = (NCG % 8 == 0) ? (blockIdx.x % 8) * (NCG / 8) + blockIdx.x / 8 : blockIdx.x;
+        // second sweep of a chunk from final rows: only when the repair by gathers would cost more
+        if (prov[k] <= gate_limit) return;
+    } else if constexpr (NCG % 8 == 0) {
+        const int slot = blockIdx.x / 8;
+        k = slot / (NCG / 8);
+        cg = (blockIdx.x % 8) * (NCG / 8) + slot % (NCG / 8);
+    } else {
+        k = blockIdx.x / NCG;
+        cg = blockIdx.x % NCG;
     }
+    const int col0 = cg * C;
+    const bool exact = exact_chunk >= 0;
+    const int a_k = ce.a[k];
+    const int w_k = exact ? a_k : ce.w[k];
+    const int a0 = exact ? a_k : a0_all;          // rows below a0 are final in memory
+    const int* pw = bnd + (size_t)(exact ? 2 * k + 1 : 2 * k) * npad;   // chain positions of the window start
+    const int* pa = bnd + (size_t)(2 * k + 1) * npad;                   // ... of the first stored row
+    const int* pe = bnd + (size_t)(2 * k + 3) * npad;                   // ... of the end of the chunk
+    int* const halo_k = halo + (size_t)k * halo_cap * npad;
+    for (int i = tid; i < PL * npad * H; i += blockDim.x) ring[i] = make_int4(-1, -1, -1, -1);  // tag -1: empty
+    for (int i = tid; i < npad; i += blockDim.x) { const int p = pw[i]; filled[i] = p; taken[i] = p; }
     __syncthreads();
     if (loader) {
         constexpr int B = F / 2;
         constexpr int MAXBUF = 32;
         constexpr int G = (NW * B <= MAXBUF) ? NW : MAXBUF / B;
         static_assert(G >= 1 && NW % G == 0, "loader groups");
-        int fl[NW], pe[NW], cs[NW];
+        int fl[NW], pend[NW], cs[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            const int k = ll + 64 * j;
-            fl[j] = pos0[k];
-            pe[j] = pos1[k];
-            cs[j] = chain_start[k];
+            const int kk = ll + 64 * j;
+            fl[j] = pw[kk];
+            pend[j] = pe[kk];
+            cs[j] = chain_start[kk];
         }
         for (int spins = 0;; ++spins) {
             bool more = false;
@@ -911,11 +996,9 @@ k_cansee_flow_cols(const int4* __restrict__ cdesc, const int* __restrict__ chain
             SW_CBAR();
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
-                if (fl[j] < pe[j]) {
+                if (fl[j] < pend[j]) {
                     more = true;
-                    int tk = taken[ll + 64 * j];
-#pragma unroll
-                    for (int s_ = 1; s_ < COLS; ++s_) { const int t2 = taken[s_ * npad + ll + 64 * j]; tk = t2 < tk ? t2 : tk; }
+                    const int tk = taken[ll + 64 * j];
                     if (fl[j] - tk <= F - B) need |= 1u << j;
                 }
             }
@@ -923,14 +1006,15 @@ k_cansee_flow_cols(const int4* __restrict__ cdesc, const int* __restrict__ chain
             if (!__ballot(need != 0)) { __builtin_amdgcn_s_sleep(2); continue; }
 #pragma unroll
             for (int g0 = 0; g0 < NW; g0 += G) {
+                // branch-free loads with clamped positions (see k_cansee_flow)
                 int bx[G * B], by[G * B], bz[G * B];
 #pragma unroll
                 for (int jj = 0; jj < G; ++jj) {
                     const int j = g0 + jj;
-                    const int last = pe[j] > 0 ? pe[j] - 1 : 0;
+                    const int last = pend[j] > 0 ? pend[j] - 1 : 0;
 #pragma unroll
                     for (int u = 0; u < B; ++u) {
-                        const int pos = fl[j] + u < pe[j] ? fl[j] + u : last;
+                        const int pos = fl[j] + u < pend[j] ? fl[j] + u : last;
                         const int4 t = cdesc[(size_t)cs[j] + pos];
                         bx[jj * B + u] = t.x; by[jj * B + u] = t.y; bz[jj * B + u] = t.z;
                     }
@@ -939,16 +1023,16 @@ k_cansee_flow_cols(const int4* __restrict__ cdesc, const int* __restrict__ chain
                 for (int jj = 0; jj < G; ++jj) {
                     const int j = g0 + jj;
                     if ((need >> j) & 1u) {
-                        const int k = ll + 64 * j;
+                        const int kk = ll + 64 * j;
                         int nf = fl[j];
 #pragma unroll
                         for (int u = 0; u < B; ++u)
-                            if (fl[j] + u < pe[j]) {
-                                fifo[(size_t)((fl[j] + u) & fm) * npad + k] = make_int4(bx[jj * B + u], by[jj * B + u], bz[jj * B + u], 0);
+                            if (fl[j] + u < pend[j]) {
+                                fifo[(size_t)((fl[j] + u) & fm) * npad + kk] = make_int4(bx[jj * B + u], by[jj * B + u], bz[jj * B + u], 0);
                                 nf = fl[j] + u + 1;
                             }
-                        SW_CBAR();
-                        filled[k] = nf;
+                        SW_CBAR();  // the entries are written before the count that publishes them (DS ops stay in order)
+                        filled[kk] = nf;
                         SW_CBAR();
                         fl[j] = nf;
                     }
@@ -957,50 +1041,91 @@ k_cansee_flow_cols(const int4* __restrict__ cdesc, const int* __restrict__ chain
         }
         return;
     }
-    // ---- workers: lane = (column s, member m)
-    const int s = tid / npad, m = tid - s * npad;
-    const int col = col0 + s;
-    u64* const myring = ring + (size_t)s * H * npad;
-    int* const mytaken = taken + s * npad;
-    char* const Lcol = reinterpret_cast<char*>(L + col);
-    int p = pos0[m];
-    const int pend = pos1[m];
-    int mine = -1, ev = -1, opar = -1, ridx = 0;
+    // ---- workers: lane = member m, columns col0 .. col0 + C - 1
+    const int m = tid;
+    const int own = m - col0;            // index of the member's own column among mine (outside [0, C): none)
+    int p = pw[m];
+    const int pend = pe[m];
+    int mine[C], oth[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { mine[c] = -1; oth[c] = -1; }
+    int ev = -1, opar = -1, ridx = 0;
+    int omode = 3;                       // 0 ring, 1 memory (final row), 2 leaf / none: `oth` holds the other-parent's values
     bool have = false;
+    unsigned n_prov = 0;
+    auto row_ptr = [&](int e) -> int* {  // where the values of event e for my columns live
+        if (e >= a_k || e < a0) {
+            if (WIDE) return L + (size_t)e * npad + col0;
+            return reinterpret_cast<int*>(reinterpret_cast<char*>(L + col0) + (unsigned)e * (unsigned)(npad * 4));
+        }
+        return halo_k + (size_t)(e - w_k) * npad + col0;   // a halo row (w_k <= e < a_k)
+    };
     if (p > 0 && p < pend) {
+        // the member's last event before the window: a final row (zone i) or a leaf (zone ii)
         const int prev = chain_ev[chain_start[m] + p - 1];
-        mine = L[(size_t)prev * npad + col];
+        if (prev < a0) {
+            const typename ColVec<C>::T t = *reinterpret_cast<const typename ColVec<C>::T*>(L + (size_t)prev * npad + col0);
+            mine[0] = t.x; mine[1] = t.y;
+            if constexpr (C == 4) { mine[2] = t.z; mine[3] = t.w; }
+        } else if (own >= 0 && own < C) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) if (c == own) mine[c] = prev;
+        }
     }
-    asm volatile("" : "+v"(mine));
+#pragma unroll
+    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(mine[c]));  // the prologue loads are complete before the loop
     for (int spins = 0;; ++spins) {
         if (spins > SPIN_LIMIT) { if ((tid & 63) == 0) atomicExch(err, 1); break; }
         SW_CBAR();
-        const u64 pr = myring[ridx];
+        int4 pr[PL];
+#pragma unroll
+        for (int h = 0; h < PL; ++h) pr[h] = ring[(size_t)h * H * npad + ridx];
         const int fcnt = filled[m];
-        SW_CBAR();
+        SW_CBAR();  // the count is read before the entry it publishes (DS operations stay in order)
         const int4 nd = fifo[((p + (have ? 1 : 0)) & fm) * npad + m];
         SW_CBAR();
         const int o = opar;
-        const int tag = (int)(unsigned)pr;
-        const bool hit = tag == o;
-        int other = hit ? (int)(pr >> 32) : -1;
-        bool ready = have && (o < 0 || hit);
-        const bool from_mem = have && o >= 0 && !hit && (o < first_event || tag > o);
+        bool hit = omode == 0;
+        int tagmax = -1;
+#pragma unroll
+        for (int h = 0; h < PL; ++h) {
+            hit = hit && pr[h].y == o && pr[h].w == o;
+            tagmax = pr[h].y > tagmax ? pr[h].y : tagmax;
+            tagmax = pr[h].w > tagmax ? pr[h].w : tagmax;
+        }
+        int other[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int rv = (c & 1) ? pr[c >> 1].z : pr[c >> 1].x;
+            other[c] = hit ? rv : oth[c];
+        }
+        bool ready = have && (omode >= 2 || hit);
+        // rare: the other-parent's row comes from memory (a final row of an earlier launch, or a ring slot
+        // that was reused: the row — real or halo — is then >= H store instructions old)
+        const bool from_mem = have && !ready && (omode == 1 || tagmax > o);
         if (__ballot(from_mem)) {
             if (from_mem) {
-                other = load_sc1_and_wait(WIDE ? &L[(size_t)o * npad + col]
-                                               : reinterpret_cast<const int*>(Lcol + (unsigned)o * (unsigned)(npad * 4)));
+                load_cols_sc1_and_wait<C>(row_ptr(o), other);
                 ready = true;
             }
         }
         if (ready) {
             const int e = ev;
-            int v = mine > other ? mine : other;
-            if (col == m) v = e;
-            mine = v;
-            if (WIDE) L[(size_t)e * npad + col] = v;
-            else *reinterpret_cast<int*>(Lcol + (unsigned)e * (unsigned)(npad * 4)) = v;
-            myring[(p & hm) * npad + m] = ((u64)(unsigned)v << 32) | (unsigned)e;
+            int v[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                v[c] = mine[c] > other[c] ? mine[c] : other[c];   // maxi(): index order == height order on one chain
+                if (c == own) v[c] = e;                            // own entry (swirld.py:220)
+                mine[c] = v[c];
+            }
+            store_cols<C>(row_ptr(e), v);
+            const int slot = (p & hm) * npad + m;
+#pragma unroll
+            for (int h = 0; h < PL; ++h) ring[(size_t)h * H * npad + slot] = make_int4(v[2 * h], e, v[2 * h + 1], e);
+            if (e >= a_k && w_k > a0) {   // a stored row of a chunk with unknown parents: count what must be repaired
+#pragma unroll
+                for (int c = 0; c < C; ++c) n_prov += (v[c] < w_k && col0 + c < n_members) ? 1u : 0u;
+            }
             ++p;
             have = false;
         }
@@ -1009,13 +1134,87 @@ k_cansee_flow_cols(const int4* __restrict__ cdesc, const int* __restrict__ chain
             opar = nd.y;
             ridx = ((nd.z >> 10) & hm) * npad + (nd.z & 1023);
             have = true;
-            mytaken[m] = p + 1;
+            taken[m] = p + 1;  // the slot may be refilled from here on
+            const int oc = (nd.z & 1023) - col0;   // the other-parent's own column among mine
+#pragma unroll
+            for (int c = 0; c < C; ++c) oth[c] = -1;
+            if (nd.y < 0) omode = 3;               // a root
+            else if (nd.y < a0) omode = 1;         // zone (i): final row in memory
+            else if (nd.y < w_k) {                 // zone (ii): a leaf
+                omode = 2;
+#pragma unroll
+                for (int c = 0; c < C; ++c) if (c == oc) oth[c] = nd.y;
+            } else omode = 0;
         }
+        // at most H - 4 store instructions of this wave in flight (the reuse argument of k_cansee_flow)
         if constexpr (H >= 32) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
         else if constexpr (H >= 16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if (!__ballot(p < pend)) break;
     }
+    if (!exact && w_k > a0) {
+        unsigned tot = n_prov;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tot += (unsigned)__shfl_xor((int)tot, off);
+        if ((tid & 63) == 0 && tot) atomicAdd(&prov[k], tot);
+    }
+}
+
+// Repair of the provisional entries of chunk k (tests/model_chunks.py fixup()): rows [a, b), window start w.
+//   T[e][c] = max(V[e][c], max over members m of T[E_m(e)][c]),  E_m(e) = F_m if V[e][m] >= w else V[e][m],
+// F_m = last event of m before w; only entries E_m(e) >= a0 matter (rows below a0 were read in full by the
+// sweep).  Every E_m(e) < w lies in an earlier chunk, repaired before this one (stream order).  One wave
+// per event; runs only when the sweep counted 0 < provisional entries <= limit.
+template <int NW>
+__global__ void __launch_bounds__(256)
+k_cansee_fixup(const int* __restrict__ chain_start, const int* __restrict__ chain_ev, const int* __restrict__ pw,
+               int a0, int w, int a, int b, int n_members, int* L, const unsigned* __restrict__ prov_k, unsigned limit,
+               unsigned* fixed_out) {
+    constexpr int npad = 64 * NW;
+    __shared__ int s_F[npad];
+    const unsigned cnt = *prov_k;
+    if (cnt == 0 || cnt > limit) return;
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        const int p = pw[i];
+        s_F[i] = p > 0 ? chain_ev[chain_start[i] + p - 1] : -1;
+    }
+    __syncthreads();
+    const int lane = lane_id();
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    unsigned fixed = 0;
+    for (int e = a + wave; e < b; e += nwaves) {
+        int V[NW], E[NW];
+        u64 pm[NW];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            V[j] = L[(size_t)e * npad + j * 64 + lane];
+            pm[j] = __ballot(V[j] < w && j * 64 + lane < n_members);
+            any = any || pm[j] != 0;
+            E[j] = V[j] >= w ? s_F[j * 64 + lane] : V[j];
+            if (E[j] < a0) E[j] = -1;
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            u64 rest = pm[j];
+            while (rest) {
+                const int cl = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const int c = j * 64 + cl;
+                int t = -1;
+#pragma unroll
+                for (int jj = 0; jj < NW; ++jj) {
+                    const int x = E[jj] >= 0 ? L[(size_t)E[jj] * npad + c] : -1;
+                    t = x > t ? x : t;
+                }
+                t = wave_max_i32(t);
+                if (lane == cl && t > V[j]) { V[j] = t; L[(size_t)e * npad + c] = t; ++fixed; }
+            }
+        }
+    }
+    if (fixed_out && fixed) atomicAdd(fixed_out, fixed);
 }
 
 // chain positions of the sub-batch cuts: out[i][m] = number of member m's events with index < cut[i]
@@ -1165,25 +1364,6 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
         B.force[i] = 0;
         B.gallop[i] = 1;
     }
-}
-
-// Wave and workgroup reductions for the resolve step.  LDS atomics on one address with a
-// different value per lane are expanded by the compiler into a 64-trip scalar loop (~2 us on the
-// critical path of every iteration): butterflies + one LDS slot per wave + ONE barrier instead.
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
 }
 
 // Step 1 (replicated, one thread per member): consume the tally results, advance the

@@ -17,6 +17,7 @@
 
 #include "../../include/swirld_hip.h"
 #include "kernels.hip.h"
+#define SW_PROV_ROWS 16   // sub-batches of one divide_rounds call that can be swept in chunks
 #include "crypto.hip.h"
 #include "exact.hip.h"
 
@@ -104,6 +105,20 @@ struct sw_ctx {
     DBuf<int4> d_cdesc;           // pool-indexed chain descriptors of the dataflow can_see sweep (same indexing as chain_ev)
     DBuf<int32_t> d_bounds;       // [cuts][npad] chain positions of the sub-batch cuts of the running divide_rounds call
     DBuf<long long> d_cuts;
+    // chunk-parallel can_see sweep (k_cansee_chunks): per chunked sub-batch 2G + 2 rows of chain positions
+    // {w_0, a_0, w_1, a_1, ..., end, end}, the halo rows' scratch table, provisional-entry counters (inside d_rb)
+    DBuf<int32_t> d_cbnd;
+    DBuf<long long> d_ccuts;
+    DBuf<int32_t> d_halo;
+    unsigned* d_prov = nullptr;   // [SW_PROV_ROWS][SW_MAX_CHUNKS] provisional entries per chunk, then [SW_PROV_ROWS] repaired entries
+    int chunks = 4;               // SW_CHUNKS: chunks swept concurrently per sub-batch (1 = the unchunked k_cansee_flow)
+    int chunk_cfg = 0;            // SW_CHUNK_CFG: 0 = 4 columns per lane, FIFO 8, ring 8; 1 = 2 columns, 8 / 16; 2 = 4 columns, 4 / 8
+    int64_t halo = 0;             // SW_HALO: events recomputed in front of a chunk (default 32 x npad: ~2.4x the age of a row's oldest entry at uniform gossip)
+    int64_t chunk_min = 16384;    // SW_CHUNK_MIN: smallest chunk worth a halo
+    bool chunks_off = false;      // set when a call had to sweep chunks twice (members silent for longer than the halo): unchunked from then on
+    struct ChunkPlan { int G = 0; int row0 = 0; int64_t a[SW_MAX_CHUNKS + 1]; int64_t w[SW_MAX_CHUNKS]; };
+    std::vector<ChunkPlan> chunk_plan;   // per sub-batch of the running call
+    std::vector<long long> ccuts_stage;  // host staging of the chunk cuts (persistent: uploaded without a sync)
     std::vector<int32_t> chain_cap;   // per member: capacity of its segment
     int64_t pool_used = 0;             // ints of the chain pool handed out
     DBuf<int32_t> d_prev_head;    // 2 x npad (ping-pong): latest divided event per member (-1 none)
@@ -166,7 +181,7 @@ struct sw_ctx {
     int BATCH = 24;    // loop iterations between host checks
     int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers; k_cansee_flow); 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
-    int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32; 10 = experiment, two columns per workgroup
+    int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
     int band_blocks = 512; // workgroups of the resolve+band kernel
@@ -647,31 +662,66 @@ int launch_cansee_flow_t(sw_ctx* c, int i, int64_t first_event) {
     return SW_OK;
 }
 
-// EXPERIMENT (SW_FLOW_CFG=10): COLS columns per workgroup, npad / COLS workgroups (k_cansee_flow_cols)
-template <int NW, int COLS, int F, int H>
-int launch_cansee_flow_cols(sw_ctx* c, int i, int64_t first_event) {
+// chunk-parallel dataflow sweep of sub-batch i (k_cansee_chunks): all chunks in ONE launch, then per chunk
+// k >= 1 the repair of its provisional entries and the second sweep — both always enqueued, both gated on
+// the device by the count the sweep left (nothing to read back, no host decision on the sweep stream)
+template <int NW, int C, int F, int H>
+int launch_cansee_chunks_t(sw_ctx* c, int i) {
     constexpr int npad = 64 * NW;
-    const size_t lds = (size_t)npad * ((size_t)F * 16 + (size_t)COLS * H * 8 + 4 + (size_t)COLS * 4);
+    constexpr int NCG = npad / C;
+    const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
+    const size_t lds = (size_t)npad * ((size_t)F * 16 + (size_t)(C / 2) * H * 16 + 8);
     const bool wide = (size_t)c->cap * (size_t)npad * sizeof(int32_t) >= (1ull << 32);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_cansee_flow_cols<NW, COLS, F, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
-        if (hipFuncSetAttribute((const void*)k_cansee_flow_cols<NW, COLS, F, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute((const void*)k_cansee_chunks<NW, C, F, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute((const void*)k_cansee_chunks<NW, C, F, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
         attr_set = true;
     }
-    const int* p0 = (const int*)c->d_bounds.p + (size_t)i * npad;
-    const int* p1 = (const int*)c->d_bounds.p + (size_t)(i + 1) * npad;
-    if (wide)
-        hipLaunchKernelGGL((k_cansee_flow_cols<NW, COLS, F, H, true>), dim3(npad / COLS), dim3(COLS * npad + 64), lds, c->stream_cs,
-                           (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, p0, p1, (const int*)c->d_chain_ev.p,
-                           (int)first_event, c->d_L.p, c->d_flow_err);
-    else
-        hipLaunchKernelGGL((k_cansee_flow_cols<NW, COLS, F, H, false>), dim3(npad / COLS), dim3(COLS * npad + 64), lds, c->stream_cs,
-                           (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, p0, p1, (const int*)c->d_chain_ev.p,
-                           (int)first_event, c->d_L.p, c->d_flow_err);
-    c->ctr.kernel_launches++;
+    ChunkEv ce{};
+    for (int k = 0; k < pl.G; ++k) { ce.w[k] = (int)pl.w[k]; ce.a[k] = (int)pl.a[k]; }
+    const int* bnd = (const int*)c->d_cbnd.p + (size_t)pl.row0 * npad;
+    unsigned* prov = c->d_prov + (size_t)i * SW_MAX_CHUNKS;
+    unsigned* fixed = c->d_prov + (size_t)SW_PROV_ROWS * SW_MAX_CHUNKS + i;
+    hipStream_t cs = c->stream_cs;
+    auto sweep = [&](int grid, int exact_chunk, unsigned limit) {
+        if (wide)
+            hipLaunchKernelGGL((k_cansee_chunks<NW, C, F, H, true>), dim3(grid), dim3(npad + 64), lds, cs,
+                               (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, bnd, ce,
+                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, c->d_halo.p, (int)c->halo, prov, limit, c->d_flow_err);
+        else
+            hipLaunchKernelGGL((k_cansee_chunks<NW, C, F, H, false>), dim3(grid), dim3(npad + 64), lds, cs,
+                               (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, bnd, ce,
+                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, c->d_halo.p, (int)c->halo, prov, limit, c->d_flow_err);
+        c->ctr.kernel_launches++;
+    };
+    sweep(pl.G * NCG, -1, 0u);
+    c->ctr.chunk_sweeps += pl.G;
+    for (int k = 1; k < pl.G; ++k) {
+        const int64_t len = pl.a[k + 1] - pl.a[k];
+        // repair by gathers up to 1/32 of the chunk's entries, a second (dependent) sweep beyond
+        const unsigned limit = (unsigned)std::min<int64_t>((len * c->n) / 32, 0x7fffffff);
+        const int blocks = (int)std::min<int64_t>((len + 3) / 4, 2048);
+        hipLaunchKernelGGL(k_cansee_fixup<NW>, dim3(blocks), dim3(256), 0, cs, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
+                           bnd + (size_t)(2 * k) * npad, (int)pl.a[0], (int)pl.w[k], (int)pl.a[k], (int)pl.a[k + 1], c->n, c->d_L.p,
+                           (const unsigned*)(prov + k), limit, fixed);
+        c->ctr.kernel_launches++;
+        sweep(NCG, k, limit);
+    }
     HIPCHK(c, hipGetLastError());
     return SW_OK;
+}
+
+template <int NW>
+int launch_cansee_chunks(sw_ctx* c, int i) {
+    if constexpr (NW <= 4) {
+        switch (c->chunk_cfg) {
+            case 1: return launch_cansee_chunks_t<NW, 2, 8, 16>(c, i);
+            case 2: return launch_cansee_chunks_t<NW, 4, 4, 8>(c, i);
+            default: return launch_cansee_chunks_t<NW, 4, 8, 8>(c, i);
+        }
+    }
+    return fail(c, SW_EINVAL, "chunked sweep: more than 256 members");
 }
 
 template <int NW, int MPL, int F, int H>
@@ -693,7 +743,6 @@ int launch_cansee_flow(sw_ctx* c, int i, int64_t first_event) {
             case 0: return launch_cansee_flow_g<NW, 1, 16, 32>(c, i, first_event);
             case 2: return launch_cansee_flow_g<NW, 1, 16, 16>(c, i, first_event);
             case 3: return launch_cansee_flow_g<NW, 1, 8, 32>(c, i, first_event);
-            case 10: return launch_cansee_flow_cols<NW, 2, 8, 16>(c, i, first_event);   // experiment: two columns per workgroup
             default: return launch_cansee_flow_g<NW, 1, 8, 16>(c, i, first_event);
         }
     }
@@ -1023,10 +1072,49 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         HIPCHK(c, hipStreamSynchronize(cs));
     }
     if (!flow) HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+    // ---- chunk plan: a sub-batch long enough is cut into G chunks that are swept concurrently, each from
+    // `halo` events before its start (k_cansee_chunks); their chain positions come from one more search kernel
+    c->chunk_plan.assign(S, sw_ctx::ChunkPlan{});
+    if (flow && np <= 256 && c->chunks > 1 && !c->chunks_off && S <= SW_PROV_ROWS) {
+        std::vector<long long>& ccuts = c->ccuts_stage;
+        ccuts.clear();
+        int max_g = 0;
+        for (int i = 0; i < S; ++i) {
+            const int64_t a = cut[i], len = cut[i + 1] - cut[i];
+            const int G = (int)std::min<int64_t>(c->chunks, len / c->chunk_min);
+            if (G < 2) continue;
+            sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
+            pl.G = G;
+            pl.row0 = (int)ccuts.size();
+            for (int k = 0; k <= G; ++k) pl.a[k] = a + len * k / G;
+            for (int k = 0; k < G; ++k) {
+                pl.w[k] = k == 0 ? a : std::max(a, pl.a[k] - c->halo);
+                ccuts.push_back(pl.w[k]);
+                ccuts.push_back(pl.a[k]);
+            }
+            ccuts.push_back(pl.a[G]);   // rows 2G and 2G + 1: the end, twice — chunk k ends at row 2k + 3 for every k
+            ccuts.push_back(pl.a[G]);
+            max_g = std::max(max_g, G);
+        }
+        if (!ccuts.empty()) {
+            CHK(dgrow(c, c->d_ccuts, ccuts.size(), 0));
+            CHK(dgrow(c, c->d_cbnd, ccuts.size() * (size_t)np, 0));
+            CHK(dgrow(c, c->d_halo, (size_t)max_g * (size_t)std::max<int64_t>(c->halo, 1) * np, 0));
+            // (pageable source: the copy is staged before the call returns)
+            HIPCHK(c, hipMemcpyAsync(c->d_ccuts.p, ccuts.data(), ccuts.size() * sizeof(long long), hipMemcpyHostToDevice, cs));
+            hipLaunchKernelGGL(k_chain_bounds, dim3((unsigned)ccuts.size()), dim3(np), 0, cs, (const int*)c->d_chain_start.p,
+                               (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, (const long long*)c->d_ccuts.p, np, c->d_cbnd.p);
+            HIPCHK(c, hipMemsetAsync(c->d_prov, 0, (size_t)SW_PROV_ROWS * (SW_MAX_CHUNKS + 1) * sizeof(unsigned), cs));
+            c->ctr.kernel_launches++;
+        }
+    }
     for (int i = 0; i < S; ++i) {
         const int64_t a = cut[i], k = cut[i + 1] - cut[i];
         Span scs{};
-        if (flow) {
+        if (flow && c->chunk_plan[i].G >= 2) {
+            scs = span_begin(c, cs);
+            CHK(launch_cansee_chunks<NW>(c, i));
+        } else if (flow) {
             scs = span_begin(c, cs);
             CHK(launch_cansee_flow<NW>(c, i, a));
         } else {
@@ -1096,6 +1184,22 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                     i, (long long)(cut[i + 1] - cut[i]), w, l, (long long)its, its ? l * 1e3 / (double)its : 0.0);
         }
         clk.mark(&c->stage_us[2]);
+        if (c->chunk_plan[i].G >= 2) {
+            // the sweep of this sub-batch is complete (the loop waited for it) and its counters came back with the
+            // loop state: provisional entries per chunk, entries the repair changed
+            const unsigned* pv = reinterpret_cast<const unsigned*>(c->h_rb + ((unsigned char*)c->d_prov - c->d_rb));
+            const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
+            for (int k = 1; k < pl.G; ++k) {
+                const unsigned cnt = pv[(size_t)i * SW_MAX_CHUNKS + k];
+                const int64_t len = pl.a[k + 1] - pl.a[k];
+                c->ctr.chunk_provisional += cnt;
+                if (cnt > (unsigned)std::min<int64_t>((len * c->n) / 32, 0x7fffffff)) {
+                    c->ctr.chunk_resweeps++;
+                    c->chunks_off = true;   // this hashgraph has members silent for longer than the halo: sweep unchunked from now on
+                }
+            }
+            c->ctr.chunk_repaired += pv[(size_t)SW_PROV_ROWS * SW_MAX_CHUNKS + i];
+        }
         // host mirror of the per-member front round (kept by the resolve kernel, read back with the loop state)
         const int R = c->R;
         for (int m = 0; m < n; ++m) c->front[m] = std::max(c->front[m], c->front_dev[m]);
@@ -1499,7 +1603,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
 // ====================================================================================
 extern "C" {
 
-int sw_version(void) { return 2; }
+int sw_version(void) { return 3; }
 
 const char* sw_last_error(const sw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1554,6 +1658,11 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
     if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
     if (const char* s = getenv("SW_FLOW_CFG")) c->flow_cfg = atoi(s);
+    if (const char* s = getenv("SW_CHUNKS")) c->chunks = std::max(1, std::min(SW_MAX_CHUNKS, atoi(s)));
+    if (const char* s = getenv("SW_CHUNK_CFG")) c->chunk_cfg = std::max(0, std::min(2, atoi(s)));
+    if (const char* s = getenv("SW_CHUNK_MIN")) c->chunk_min = std::max(64, atoi(s));
+    c->halo = 32 * (int64_t)c->npad;
+    if (const char* s = getenv("SW_HALO")) c->halo = std::max(0, atoi(s));
     if (const char* s = getenv("SW_ELECT_IMPL")) c->elect_impl = atoi(s);
     if (const char* s = getenv("SW_GALLOP")) c->gallop_after = std::max(0, atoi(s));
     if (const char* s = getenv("SW_SKIP")) c->skip = std::max(0, std::min(32, atoi(s)));
@@ -1619,13 +1728,15 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     }
     {
         static_assert(2 * sizeof(RState) + sizeof(int) <= 256, "readback block header");
-        c->rb_bytes = 256 + (size_t)c->npad * sizeof(int32_t);
+        const size_t prov_off = 256 + (size_t)c->npad * sizeof(int32_t);
+        c->rb_bytes = prov_off + (size_t)SW_PROV_ROWS * (SW_MAX_CHUNKS + 1) * sizeof(unsigned);
         CHIP(hipMalloc((void**)&c->d_rb, c->rb_bytes));
         CHIP(hipMemset(c->d_rb, 0, c->rb_bytes));
         CHIP(hipHostMalloc((void**)&c->h_rb, c->rb_bytes, hipHostMallocDefault));
         c->d_state = reinterpret_cast<RState*>(c->d_rb);
         c->d_flow_err = reinterpret_cast<int*>(c->d_rb + 2 * sizeof(RState));
         c->d_front.p = reinterpret_cast<int32_t*>(c->d_rb + 256);
+        c->d_prov = reinterpret_cast<unsigned*>(c->d_rb + prov_off);
     }
     CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
 
@@ -2508,6 +2619,7 @@ int sw_reset(sw_ctx* c) {
     if (c->stream_io) HIPCHK(c, hipStreamSynchronize(c->stream_io));  // a payload upload may still be writing t / sig
     c->payload_pending = false;
     c->exact = false;  // (a fresh hashgraph starts on the fast path again)
+    c->chunks_off = false;  // ... and with the chunked sweep
     return SW_OK;
 }
 

@@ -26,6 +26,11 @@ def test_random_shapes(pkg, monkeypatch, seed):
     monkeypatch.setenv("SW_SKIP", str(int(rng.choice([0, 1, 2, 2, 3, 7]))))
     if rng.random() < 0.25:
         monkeypatch.setenv("SW_GALLOP", str(int(rng.choice([1, 2, 3]))))
+    if rng.random() < 0.5:  # chunk-parallel sweep at toy sizes (only the dataflow variant 6 chunks)
+        monkeypatch.setenv("SW_CHUNKS", str(int(rng.choice([2, 3, 4, 8]))))
+        monkeypatch.setenv("SW_CHUNK_MIN", str(int(rng.choice([64, 300, 1000]))))
+        monkeypatch.setenv("SW_HALO", str(int(rng.choice([0, 5, 100, 2000]))))
+        monkeypatch.setenv("SW_CHUNK_CFG", str(int(rng.choice([0, 1, 2]))))
     cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 9000 + seed, mode, p0, p1)
     t = t + rng.integers(0, 3, N) * 0.5
     stake = None
