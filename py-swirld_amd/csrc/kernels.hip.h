@@ -1041,24 +1041,30 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
         }
         return;
     }
-    // ---- workers: lane = member m, columns col0 .. col0 + C - 1
+    // ---- workers: lane = member m, columns col0 .. col0 + C - 1.  The trip is kept branch-light: the
+    // classification of an other-parent, the own-column overwrite and the provisional test are selects.
     const int m = tid;
     const int own = m - col0;            // index of the member's own column among mine (outside [0, C): none)
     int p = pw[m];
     const int pend = pe[m];
-    int mine[C], oth[C];
+    int mine[C], oth[C], nm[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) { mine[c] = -1; oth[c] = -1; }
+    for (int c = 0; c < C; ++c) { mine[c] = -1; oth[c] = -1; nm[c] = (c == own) ? 0 : -1; }   // e | nm[c] = e in the own column, -1 elsewhere
     int ev = -1, opar = -1, ridx = 0;
-    int omode = 3;                       // 0 ring, 1 memory (final row), 2 leaf / none: `oth` holds the other-parent's values
+    int mode = 2;                        // 0: poll the ring, 1: final row in memory, 2: `oth` already holds the other-parent's values (leaf, root)
     bool have = false;
     unsigned n_prov = 0;
-    auto row_ptr = [&](int e) -> int* {  // where the values of event e for my columns live
-        if (e >= a_k || e < a0) {
-            if (WIDE) return L + (size_t)e * npad + col0;
-            return reinterpret_cast<int*>(reinterpret_cast<char*>(L + col0) + (unsigned)e * (unsigned)(npad * 4));
-        }
-        return halo_k + (size_t)(e - w_k) * npad + col0;   // a halo row (w_k <= e < a_k)
+    const bool count_prov = !exact && w_k > a0;
+    // where the values of event e for my columns live: the table, or the scratch rows of the halo
+    // (w_k <= e < a_k).  Selects on integers, not branches on pointers.
+    const unsigned long long Lb = reinterpret_cast<unsigned long long>(L + col0);
+    const unsigned long long Hb = reinterpret_cast<unsigned long long>(halo_k + col0);
+    auto row_ptr = [&](int e) -> int* {
+        const bool in_table = e >= a_k || e < a0;
+        const unsigned long long base = in_table ? Lb : Hb;
+        const unsigned row = (unsigned)(in_table ? e : e - w_k);
+        if (WIDE) return reinterpret_cast<int*>(base + (unsigned long long)row * (unsigned long long)(npad * 4));
+        return reinterpret_cast<int*>(base + (unsigned long long)(row * (unsigned)(npad * 4)));
     };
     if (p > 0 && p < pend) {
         // the member's last event before the window: a final row (zone i) or a leaf (zone ii)
@@ -1067,9 +1073,9 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
             const typename ColVec<C>::T t = *reinterpret_cast<const typename ColVec<C>::T*>(L + (size_t)prev * npad + col0);
             mine[0] = t.x; mine[1] = t.y;
             if constexpr (C == 4) { mine[2] = t.z; mine[3] = t.w; }
-        } else if (own >= 0 && own < C) {
+        } else {
 #pragma unroll
-            for (int c = 0; c < C; ++c) if (c == own) mine[c] = prev;
+            for (int c = 0; c < C; ++c) mine[c] = prev | nm[c];
         }
     }
 #pragma unroll
@@ -1085,24 +1091,21 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
         const int4 nd = fifo[((p + (have ? 1 : 0)) & fm) * npad + m];
         SW_CBAR();
         const int o = opar;
-        bool hit = omode == 0;
-        int tagmax = -1;
+        int diff = 0;                    // every tag of every plane must be the wanted event
 #pragma unroll
-        for (int h = 0; h < PL; ++h) {
-            hit = hit && pr[h].y == o && pr[h].w == o;
-            tagmax = pr[h].y > tagmax ? pr[h].y : tagmax;
-            tagmax = pr[h].w > tagmax ? pr[h].w : tagmax;
-        }
+        for (int h = 0; h < PL; ++h) diff |= (pr[h].y ^ o) | (pr[h].w ^ o);
+        const bool hit = diff == 0;      // (an event outside the window is never in the ring; a root polls nothing it uses)
         int other[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int rv = (c & 1) ? pr[c >> 1].z : pr[c >> 1].x;
-            other[c] = hit ? rv : oth[c];
+            other[c] = mode == 0 ? (hit ? rv : -1) : oth[c];
         }
-        bool ready = have && (omode >= 2 || hit);
+        bool ready = have && (mode == 2 || (mode == 0 && hit));
         // rare: the other-parent's row comes from memory (a final row of an earlier launch, or a ring slot
-        // that was reused: the row — real or halo — is then >= H store instructions old)
-        const bool from_mem = have && !ready && (omode == 1 || tagmax > o);
+        // that was reused — plane 0 is written first, so its tag is the newest: the row, real or halo, is
+        // then >= H store instructions old)
+        const bool from_mem = have && !ready && (mode == 1 || pr[0].y > o);
         if (__ballot(from_mem)) {
             if (from_mem) {
                 load_cols_sc1_and_wait<C>(row_ptr(o), other);
@@ -1114,17 +1117,23 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
             int v[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                v[c] = mine[c] > other[c] ? mine[c] : other[c];   // maxi(): index order == height order on one chain
-                if (c == own) v[c] = e;                            // own entry (swirld.py:220)
-                mine[c] = v[c];
+                // maxi(): index order == height order on one chain; the own entry (swirld.py:220) is e itself,
+                // larger than every ancestor
+                const int oe = e | nm[c];
+                int t = mine[c] > other[c] ? mine[c] : other[c];
+                t = t > oe ? t : oe;
+                v[c] = t;
+                mine[c] = t;
             }
             store_cols<C>(row_ptr(e), v);
             const int slot = (p & hm) * npad + m;
 #pragma unroll
             for (int h = 0; h < PL; ++h) ring[(size_t)h * H * npad + slot] = make_int4(v[2 * h], e, v[2 * h + 1], e);
-            if (e >= a_k && w_k > a0) {   // a stored row of a chunk with unknown parents: count what must be repaired
+            if (count_prov) {   // a stored row of a chunk with unknown parents: count the stores that hold something to repair
+                int vmin = 0x7fffffff;
 #pragma unroll
-                for (int c = 0; c < C; ++c) n_prov += (v[c] < w_k && col0 + c < n_members) ? 1u : 0u;
+                for (int c = 0; c < C; ++c) if (col0 + c < n_members) vmin = v[c] < vmin ? v[c] : vmin;
+                n_prov += (e >= a_k && vmin < w_k) ? 1u : 0u;
             }
             ++p;
             have = false;
@@ -1135,16 +1144,14 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
             ridx = ((nd.z >> 10) & hm) * npad + (nd.z & 1023);
             have = true;
             taken[m] = p + 1;  // the slot may be refilled from here on
+            // zone of the other-parent: (i) final row in memory, (ii) a leaf {creator: event}, (iii) in the window; a root has none
+            const int y = nd.y;
+            const bool leaf = y >= a0 && y < w_k;
+            mode = y < 0 ? 2 : (y < a0 ? 1 : (leaf ? 2 : 0));
             const int oc = (nd.z & 1023) - col0;   // the other-parent's own column among mine
+            const int lv = leaf ? y : -1;
 #pragma unroll
-            for (int c = 0; c < C; ++c) oth[c] = -1;
-            if (nd.y < 0) omode = 3;               // a root
-            else if (nd.y < a0) omode = 1;         // zone (i): final row in memory
-            else if (nd.y < w_k) {                 // zone (ii): a leaf
-                omode = 2;
-#pragma unroll
-                for (int c = 0; c < C; ++c) if (c == oc) oth[c] = nd.y;
-            } else omode = 0;
+            for (int c = 0; c < C; ++c) oth[c] = (c == oc) ? lv : -1;
         }
         // at most H - 4 store instructions of this wave in flight (the reuse argument of k_cansee_flow)
         if constexpr (H >= 32) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
@@ -1156,7 +1163,7 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
         unsigned tot = n_prov;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) tot += (unsigned)__shfl_xor((int)tot, off);
-        if ((tid & 63) == 0 && tot) atomicAdd(&prov[k], tot);
+        if ((tid & 63) == 0 && tot) atomicAdd(&prov[k], tot);   // (counted in STORES: up to C entries each)
     }
 }
 

@@ -699,8 +699,9 @@ int launch_cansee_chunks_t(sw_ctx* c, int i) {
     c->ctr.chunk_sweeps += pl.G;
     for (int k = 1; k < pl.G; ++k) {
         const int64_t len = pl.a[k + 1] - pl.a[k];
-        // repair by gathers up to 1/32 of the chunk's entries, a second (dependent) sweep beyond
-        const unsigned limit = (unsigned)std::min<int64_t>((len * c->n) / 32, 0x7fffffff);
+        // repair by gathers up to 1/32 of the chunk's entries, a second (dependent) sweep beyond (the sweep counts
+        // provisional STORES of C columns each)
+        const unsigned limit = (unsigned)std::min<int64_t>((len * c->n) / (32 * C), 0x7fffffff);
         const int blocks = (int)std::min<int64_t>((len + 3) / 4, 2048);
         hipLaunchKernelGGL(k_cansee_fixup<NW>, dim3(blocks), dim3(256), 0, cs, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
                            bnd + (size_t)(2 * k) * npad, (int)pl.a[0], (int)pl.w[k], (int)pl.a[k], (int)pl.a[k + 1], c->n, c->d_L.p,
@@ -1193,7 +1194,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                 const unsigned cnt = pv[(size_t)i * SW_MAX_CHUNKS + k];
                 const int64_t len = pl.a[k + 1] - pl.a[k];
                 c->ctr.chunk_provisional += cnt;
-                if (cnt > (unsigned)std::min<int64_t>((len * c->n) / 32, 0x7fffffff)) {
+                if (cnt > (unsigned)std::min<int64_t>((len * c->n) / (32 * (c->chunk_cfg == 1 ? 2 : 4)), 0x7fffffff)) {
                     c->ctr.chunk_resweeps++;
                     c->chunks_off = true;   // this hashgraph has members silent for longer than the halo: sweep unchunked from now on
                 }
