@@ -181,9 +181,14 @@ def main():
     npad = ((n + 63) // 64) * 64
     cs_impl = int(os.environ.get("SW_CANSEE_IMPL", "6" if npad <= 256 else "3"))
     cs_name = "k_cansee_flow" if cs_impl >= 6 else ("k_cansee_member1b" if npad <= 256 else "k_cansee_stream")
+    cs_note = "12n B per event (2 parent rows read, 1 written); bound by the dependency chain of the DAG (about 3.4 N/n levels)"
+    if cd.get("chunk_sweeps", 0) > 0:  # the chunk-parallel sweep ran (k_cansee_chunks: the launch's span includes its gated repair kernels)
+        cs_name = "k_cansee_chunks"
+        cs_note = ("12n B per event (2 parent rows read, 1 written); %d chunks swept concurrently in %d launches, each from a halo of "
+                   "32 npad events: the dependency chain per launch is the chunk's, not the sub-batch's; %d provisional entries, "
+                   "%d chunks swept twice" % (cd["chunk_sweeps"], tm["cansee_launches"], cd["chunk_provisional"], cd["chunk_resweeps"]))
     kernels = [
-        fam(cs_name, tm["cansee_launches"], tm["cansee_kernel_ms"], 12 * n * (N - n), "hbm",
-            "12n B per event (2 parent rows read, 1 written); bound by the dependency chain of the DAG (about 3.4 N/n levels)"),
+        fam(cs_name, tm["cansee_launches"], tm["cansee_kernel_ms"], 12 * n * (N - n), "hbm", cs_note),
         fam("k_resolve_band", tm["resolve_launches"], tm["resolve_ms"], cd["band_events"] * (4 * n + n // 8), "hbm/L2",
             "4n B read + n/8 B written per band event; the replicated resolve step (latency) dominates its time"),
         fam("k_tally_bits", tm["tally_launches"], tm["tally_ms"], cd["tally_evals"] * (4 * n + n * n // 8 + 8), "L2",
@@ -206,7 +211,8 @@ def main():
         "path_note": "whole-pass algorithmic bytes (SURVEY.md §8d) / ms_per_step: the path is bound by its dependency "
                      "chains (DAG levels, rounds), not by bandwidth",
         "counters": {k: cd[k] for k in ("levels", "round_iterations", "tally_evals", "band_events", "voter_evals",
-                                        "majority_evals", "coin_votes", "coin_flips", "far_hops")},
+                                        "majority_evals", "coin_votes", "coin_flips", "far_hops",
+                                        "chunk_sweeps", "chunk_provisional", "chunk_repaired", "chunk_resweeps")},
         "phase_ms": {k: round(v, 3) for k, v in (("can_see_stream_span", tm["can_see_ms"]), ("round_loop_span", tm["rounds_ms"]),
                                                  ("aux_finalize_voter_span", tm["finalize_ms"]), ("fame", tm["fame_ms"]))},
         "phase_note": "profiled pass = plain launches with event pairs (slower than the graph-replayed timed steps); "

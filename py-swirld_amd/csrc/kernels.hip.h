@@ -1323,6 +1323,9 @@ struct LoopBufs {
     int* evalround;   // [2][npad] round in which the member's chain was last exhausted
     int* evalpos;     // [2][npad] ... and up to which position
     int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
+    u64* found64;     // [2][npad] the same minimum as {event << 32 | last candidate of the window that would follow it
+                      // (0xffffffff: not known)}: what k_resolve_band needs about the passing candidate without two
+                      // dependent look-ups (the candidate table, the chain index) at its head; ~0: none
     int* farslot;     // [2][npad] smallest candidate slot that was FAR (not tallied; INF: none)
     int* force;       // [2][npad] tally the member's cursor candidate even though it is far
     int* cand;        // [2][npad][64] candidate table of the next tally launch: entry 1 + j = event of
@@ -1367,6 +1370,7 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
     for (int i = threadIdx.x; i < 2 * npad; i += blockDim.x) {
         B.unres[i] = 0;
         B.found[i] = SW_INF;
+        B.found64[i] = ~0ull;
         B.farslot[i] = SW_INF;
         B.force[i] = 0;
         B.gallop[i] = 1;
@@ -1389,9 +1393,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
     __shared__ int s_res[1024];   // ... and whether it is
     __shared__ int s_cp[1024];    // chain_ev index of b's cursor candidate (-1: chain exhausted)
+    __shared__ int s_ce[1024];    // chain_ev index one past b's last visible event
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.lo_next); pin_arg(B.pos_next);
-    pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
+    pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found); pin_arg(B.found64); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
     pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
     pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
@@ -1414,6 +1419,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     int un = member ? B.unres[in + c] : 0;
     int curc = member ? B.cur[in + c] : 0;
     const int fnd = member ? B.found[in + c] : SW_INF;
+    const u64 fev = member ? B.found64[in + c] : ~0ull;
     const int jf = member ? B.farslot[in + c] : SW_INF;
     int frc = member ? B.force[in + c] : 0;
     const int gsv = member ? B.gallop[in + c] : 1;
@@ -1470,15 +1476,17 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         if (fnd != SW_INF && fnd < jf) {
             if (strd == 1 || fnd == 0) {
                 my_pos_next = curc + fnd * strd;
-                // = chain_ev[cs + my_pos_next], from the window the previous launch published for this
-                // member (an L2 hit instead of a miss on the chain index)
-                my_lo_next = B.cand[((size_t)par * npad + c) * 64 + 1 + fnd];
-                // the next round's window of this member starts here; fetch its last candidate in the
-                // same memory round trip (used for the band range if the round is entered right away)
+                // = chain_ev[cs + my_pos_next]: the passing tally published the event itself (the minimum
+                // over events is the minimum over slots: one chain) — no look-up behind `fnd`
+                my_lo_next = (int)(fev >> 32);
+                // the next round's window of this member starts here; its last candidate (the band range,
+                // if the round is entered right away) came with the event when the published window reached
+                // that far, else it is fetched here (end of the visible chain, strided windows)
                 {   // (the window of the next round: offset by `skip` when that leaves a candidate)
                     const int w0 = my_pos_next + skip < clen ? my_pos_next + skip : my_pos_next;
                     spec_cur = w0;
-                    spec_last = chain_ev[cs + (clen - w0 < K ? clen : w0 + K) - 1];
+                    const int pl = (int)(uint32_t)fev;
+                    spec_last = (pl >= 0 && strd == 1) ? pl : chain_ev[cs + (clen - w0 < K ? clen : w0 + K) - 1];
                 }
                 un = 0;
             } else {  // bracketed by a strided window: look at (slot fnd-1, slot fnd] next
@@ -1640,6 +1648,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         if (member) {
             s_thr[c] = thr;
             s_cp[c] = live ? cs + curc : -1;  // (the three arrays are free again after the inheritance step)
+            s_ce[c] = cs + clen;
             s_ln[c] = live;
             s_res[c] = strd;
         }
@@ -1654,14 +1663,19 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // Candidate table for the tally (saves it a dependent round trip): workgroup b publishes the
     // window of member b.  The load is issued here and the store deferred behind the band rows, so
     // that it costs this kernel no round trip of its own.
-    const int KPS = K < 32 ? 32 : 64;
+    // Entries 1 .. K are the candidates; a contiguous window is published up to 63 positions far (never tallied:
+    // the tally of slot j hands entry j + skip + K — the last candidate of the window that would follow slot
+    // j — on to the next resolve step together with its verdict).
+    const int KPS = 64;
     int cand_v = -1;
     const bool cand_mine = (int)blockIdx.x < npad && (int)threadIdx.x < KPS;
     {
         auto window = [&](int m) -> int {
             const int j = (int)threadIdx.x - 1;
-            const int base = s_cp[m], lv = s_ln[m];
-            return (base >= 0 && j >= 0 && j < lv) ? chain_ev[base + j * s_res[m]] : -1;
+            const int base = s_cp[m], lv = s_ln[m], st_ = s_res[m];
+            if (base < 0 || j < 0) return -1;
+            if (j < lv) return chain_ev[base + j * st_];
+            return (st_ == 1 && base + j < s_ce[m]) ? chain_ev[base + j] : -1;   // look-ahead (visible events only)
         };
         if (cand_mine) cand_v = window(blockIdx.x);
         if ((int)threadIdx.x < KPS)  // fewer workgroups than members (tuning runs): the rest right away
@@ -1697,6 +1711,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             B.evalpos[out + c] = evp_now;
             B.lo_r[out + c] = thr;
             B.found[out + c] = SW_INF;
+            B.found64[out + c] = ~0ull;
             B.farslot[out + c] = SW_INF;
             B.force[out + c] = frc;
             B.gallop[out + c] = strd | (miss << 8) | (skp << 16);
@@ -1867,7 +1882,10 @@ k_tally_candidates(LoopBufs B, int par, int K,
 #pragma unroll
     for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(3u * hits[j] > tot2));
     if (lane == 0) {
-        if (3u * cnt > tot2) atomicMin(&found[cm], cj);  // count of members vs the STAKE threshold (Q2)
+        if (3u * cnt > tot2) {  // count of members vs the STAKE threshold (Q2)
+            atomicMin(&found[cm], cj);
+            atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]), ((u64)(uint32_t)e << 32) | 0xffffffffull);
+        }
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
 }
@@ -2082,7 +2100,7 @@ __device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) +
 
 template <int NW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 4 ? 8 : 2, 8)))
-k_tally_bits(LoopBufs B, int par, int K,
+k_tally_bits(LoopBufs B, int par, int K, int skip,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
              const int* __restrict__ chain_ev,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
@@ -2094,7 +2112,7 @@ k_tally_bits(LoopBufs B, int par, int K,
     __shared__ __attribute__((aligned(16))) int s_pk[4][Gm::PK_INTS];
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.found); pin_arg(B.farslot);
-    pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand); pin_arg(par); pin_arg(K);
+    pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand); pin_arg(B.found64); pin_arg(B.gallop); pin_arg(par); pin_arg(K); pin_arg(skip);
     pin_arg(L); pin_arg(sp); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
@@ -2111,6 +2129,11 @@ k_tally_bits(LoopBufs B, int par, int K,
     const int un = B.unres[pb + cm], frc = B.force[pb + cm];
     const int* cand = B.cand + ((size_t)(1 - par) * npad + cm) * 64;
     const int e = cand[cj + 1];  // published by k_resolve_band (-1: no such candidate)
+    // what the next resolve step will want if this slot is the member's first passing one: the last candidate of
+    // the window that would follow it (entry j + skip + K of a contiguous window's look-ahead; -1: not published)
+    const int la_i = cj + skip + K;
+    const int la = la_i < 64 ? cand[la_i < 64 ? la_i : 63] : -1;
+    const int gsv = B.gallop[pb + cm];
     int thr[NW], P[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
@@ -2181,7 +2204,11 @@ k_tally_bits(LoopBufs B, int par, int K,
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
     if (lane == 0) {
-        if (3u * cnt > tot2) atomicMin(&found[cm], cj);  // count of members vs the STAKE threshold (Q2)
+        if (3u * cnt > tot2) {  // count of members vs the STAKE threshold (Q2)
+            atomicMin(&found[cm], cj);
+            const uint32_t pl = ((gsv & 0xff) == 1 && la >= 0) ? (uint32_t)la : 0xffffffffu;
+            atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]), ((u64)(uint32_t)e << 32) | pl);
+        }
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
     SW_STAMP(stamp, it_, sb + 5);
