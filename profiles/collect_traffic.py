@@ -27,7 +27,7 @@ def per_kernel(d, counter, kernel):
     if not len(sel):
         return None
     live = sel[sel > sel.max() * 0.05]
-    return {"dispatches": int(sel.count()), "live": int(live.count()), "mean_live_KiB": float(live.mean()),
+    return {"dispatches": int(sel.count()), "live": int(live.count()), "mean_live_KiB": float(live.mean()) if len(live) else 0.0,
             "sum_KiB": float(sel.sum())}
 
 
