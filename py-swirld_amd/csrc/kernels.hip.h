@@ -1322,10 +1322,11 @@ struct LoopBufs {
     int* pos_next;    // [2][npad] ... and its chain position
     int* evalround;   // [2][npad] round in which the member's chain was last exhausted
     int* evalpos;     // [2][npad] ... and up to which position
-    int* found;       // [2][npad] smallest candidate slot whose tally passed (INF: none)
-    u64* found64;     // [2][npad] the same minimum as {event << 32 | last candidate of the window that would follow it
-                      // (0xffffffff: not known)}: what k_resolve_band needs about the passing candidate without two
-                      // dependent look-ups (the candidate table, the chain index) at its head; ~0: none
+    u64* found64;     // [2][npad] the member's first candidate whose tally passed, as ONE key an atomicMin can order:
+                      // {event << 32 | slot << 26 | (last candidate of the window that would follow it) - event}
+                      // (low field 0x3ffffff: not known; ~0: no candidate passed).  The minimum over events is the
+                      // minimum over slots (one chain), and k_resolve_band gets the event and the look-ahead without
+                      // two dependent look-ups (candidate table, chain index) at its head.
     int* farslot;     // [2][npad] smallest candidate slot that was FAR (not tallied; INF: none)
     int* force;       // [2][npad] tally the member's cursor candidate even though it is far
     int* cand;        // [2][npad][64] candidate table of the next tally launch: entry 1 + j = event of
@@ -1369,7 +1370,6 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
     }
     for (int i = threadIdx.x; i < 2 * npad; i += blockDim.x) {
         B.unres[i] = 0;
-        B.found[i] = SW_INF;
         B.found64[i] = ~0ull;
         B.farslot[i] = SW_INF;
         B.force[i] = 0;
@@ -1396,7 +1396,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     __shared__ int s_ce[1024];    // chain_ev index one past b's last visible event
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.lo_next); pin_arg(B.pos_next);
-    pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found); pin_arg(B.found64); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
+    pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found64); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
     pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
     pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
@@ -1418,8 +1418,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     const int clen = member ? chain_len[c] : 0;  // events of member c visible to this run
     int un = member ? B.unres[in + c] : 0;
     int curc = member ? B.cur[in + c] : 0;
-    const int fnd = member ? B.found[in + c] : SW_INF;
     const u64 fev = member ? B.found64[in + c] : ~0ull;
+    const int fnd = fev == ~0ull ? SW_INF : (int)((fev >> 26) & 63);   // smallest candidate slot whose tally passed
     const int jf = member ? B.farslot[in + c] : SW_INF;
     int frc = member ? B.force[in + c] : 0;
     const int gsv = member ? B.gallop[in + c] : 1;
@@ -1485,8 +1485,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                 {   // (the window of the next round: offset by `skip` when that leaves a candidate)
                     const int w0 = my_pos_next + skip < clen ? my_pos_next + skip : my_pos_next;
                     spec_cur = w0;
-                    const int pl = (int)(uint32_t)fev;
-                    spec_last = (pl >= 0 && strd == 1) ? pl : chain_ev[cs + (clen - w0 < K ? clen : w0 + K) - 1];
+                    const int dl = (int)(fev & 0x3ffffffull);
+                    spec_last = (dl != 0x3ffffff && strd == 1) ? my_lo_next + dl : chain_ev[cs + (clen - w0 < K ? clen : w0 + K) - 1];
                 }
                 un = 0;
             } else {  // bracketed by a strided window: look at (slot fnd-1, slot fnd] next
@@ -1710,7 +1710,6 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             B.evalround[out + c] = evr_now;
             B.evalpos[out + c] = evp_now;
             B.lo_r[out + c] = thr;
-            B.found[out + c] = SW_INF;
             B.found64[out + c] = ~0ull;
             B.farslot[out + c] = SW_INF;
             B.force[out + c] = frc;
@@ -1818,7 +1817,6 @@ k_tally_candidates(LoopBufs B, int par, int K,
     const size_t pb = (size_t)(1 - par) * npad;
     const int* unres = B.unres + pb;
     const int* lo_r = B.lo_r + pb;
-    int* found = B.found + pb;
     if (st->done) return;
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
@@ -1882,10 +1880,9 @@ k_tally_candidates(LoopBufs B, int par, int K,
 #pragma unroll
     for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(3u * hits[j] > tot2));
     if (lane == 0) {
-        if (3u * cnt > tot2) {  // count of members vs the STAKE threshold (Q2)
-            atomicMin(&found[cm], cj);
-            atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]), ((u64)(uint32_t)e << 32) | 0xffffffffull);
-        }
+        if (3u * cnt > tot2)  // count of members vs the STAKE threshold (Q2)
+            atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]),
+                      ((u64)(uint32_t)e << 32) | ((u64)cj << 26) | 0x3ffffffull);
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
 }
@@ -2110,17 +2107,25 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
     using Gm = BitsGeom<NW>;
     __shared__ __attribute__((aligned(16))) int s_pk[4][Gm::PK_INTS];
+    __shared__ u64 s_key[4];
+    __shared__ int s_fark[4], s_cm[4];
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
-    pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.found); pin_arg(B.farslot);
+    pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.farslot);
     pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand); pin_arg(B.found64); pin_arg(B.gallop); pin_arg(par); pin_arg(K); pin_arg(skip);
     pin_arg(L); pin_arg(sp); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
-    int* found = B.found + pb;
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
     const int wv = blockIdx.x * 4 + wib;
     const int cm = wv / K, cj = wv - cm * K;  // member, candidate slot
+    // The verdict of this wave: `key` (its tally passed) or `fark` (a FAR candidate).  Verdicts go to the
+    // member's words by atomicMin — ~7000 waves on ~24 cache lines serialise at the memory side (3-5 us
+    // of kernel tail, measured with the phase stamps); the four waves of a workgroup are (mostly) four
+    // consecutive slots of ONE member, so they reduce in LDS first and one lane speaks for them.
+    u64 key = ~0ull;
+    int fark = SW_INF;
+    u64 nfar = 0;
     // Round trip 1: everything addressed by the launch parameters alone, issued before the first
     // branch — including the candidate, from the table k_resolve_band published (creator(e) = cm
     // by construction).  Round trip 2: its can_see row and both parents.  Round trip 3: the
@@ -2143,7 +2148,8 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     const int it_ = stamp ? st->iter - 1 : 0;
     if (stamp && !s_done && it_ < SW_DBG_MAX_ITERS) B.dbg[(size_t)it_ * 32 + sb] = wall_clock64();
     SW_STAMP(stamp && !s_done, it_, sb + 1);
-    if (s_done || !un || e < 0) return;
+    if (s_done) return;   // (uniform over the grid: no wave of this workgroup reaches the barrier below)
+    if (un && e >= 0) do {
     const int ce = cm;
     int* pk = s_pk[wib];
     SW_STAMP(stamp, it_, sb + 2);
@@ -2152,12 +2158,8 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     for (int j = 0; j < NW; ++j) P[j] = L[(size_t)e * npad + j * 64 + lane];
     SW_STAMP(stamp, it_, sb + 3);
     // FAR candidate (a parent beyond the band): decided by inheritance in k_resolve_band
-    if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && frc)) {
-        if (lane == 0) atomicMin(&B.farslot[pb + cm], cj);
-        return;
-    }
+    if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && frc)) { fark = cj; break; }
     u64 farm[NW];
-    u64 nfar = 0;
     uint32_t nvalid = 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
@@ -2173,7 +2175,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     }
     // necessary condition: a member is strongly seen only through more than 2T/3 (unit-stake)
     // hops, so with fewer valid hops no column can pass — skip the gathers altogether
-    if (3u * nvalid <= tot2) return;
+    if (3u * nvalid <= tot2) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int w = lane % W32, g = lane / W32;
@@ -2203,11 +2205,21 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     uint32_t cnt = (g == 0) ? __popc(gt) : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    if (3u * cnt > tot2) {  // count of members vs the STAKE threshold (Q2)
+        const int dl = ((gsv & 0xff) == 1 && la >= 0 && la - e < 0x3ffffff) ? la - e : 0x3ffffff;
+        key = ((u64)(uint32_t)e << 32) | ((u64)cj << 26) | (u64)dl;
+    }
+    } while (0);
+    if (lane == 0) { s_key[wib] = key; s_fark[wib] = fark; s_cm[wib] = cm; }
+    __syncthreads();
     if (lane == 0) {
-        if (3u * cnt > tot2) {  // count of members vs the STAKE threshold (Q2)
-            atomicMin(&found[cm], cj);
-            const uint32_t pl = ((gsv & 0xff) == 1 && la >= 0) ? (uint32_t)la : 0xffffffffu;
-            atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]), ((u64)(uint32_t)e << 32) | pl);
+        if (wib == 0 || s_cm[wib - 1] != cm) {   // the first wave of a member in this workgroup speaks for the member's waves
+            for (int w2 = wib + 1; w2 < 4 && s_cm[w2] == cm; ++w2) {
+                key = s_key[w2] < key ? s_key[w2] : key;
+                fark = s_fark[w2] < fark ? s_fark[w2] : fark;
+            }
+            if (key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]), key);
+            if (fark != SW_INF) atomicMin(&B.farslot[pb + cm], fark);
         }
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }

@@ -153,9 +153,9 @@ struct sw_ctx {
     hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr;
     std::vector<int32_t> divided_cnt;   // per member: events already divided (chain positions below `divided`)
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
-    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_found, d_farslot, d_force, d_cand, d_gallop;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
-    DBuf<u64> d_found64;   // [2][npad] {event << 32 | look-ahead} of the members' first passing candidates (LoopBufs::found64)
+    DBuf<u64> d_found64;   // [2][npad] {event << 32 | slot << 26 | look-ahead} of the members' first passing candidates (LoopBufs::found64)
     // one device block read back with ONE copy per round-loop shot: loop state (x2), sweep error flag, per-member
     // front rounds; and its pinned host mirror
     unsigned char* d_rb = nullptr;
@@ -757,7 +757,6 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.st = c->d_state;
     B.lo_r = c->d_lo_r.p; B.cur = c->d_cur.p; B.unres = c->d_unres.p; B.lo_next = c->d_lo_next.p;
     B.pos_next = c->d_pos_next.p; B.evalround = c->d_evalround.p; B.evalpos = c->d_evalpos.p;
-    B.found = c->d_found.p;
     B.found64 = c->d_found64.p;
     B.farslot = c->d_farslot.p;
     B.force = c->d_force.p;
@@ -1753,7 +1752,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_unres, 2 * np, 0));
     CCHK(dgrow(c, c->d_lo_next, 2 * np, 0));
     CCHK(dgrow(c, c->d_pos_next, 2 * np, 0));
-    CCHK(dgrow(c, c->d_found, 2 * np, 0));
     CCHK(dgrow(c, c->d_found64, 2 * np, 0));
     CCHK(dgrow(c, c->d_farslot, 2 * np, 0));
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
@@ -1778,7 +1776,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(fill_i32(c, c->d_cur.p, 2 * np, 0));
     CCHK(fill_i32(c, c->d_lo_next.p, 2 * np, SW_INF));
     CCHK(fill_i32(c, c->d_pos_next.p, 2 * np, 0));
-    CCHK(fill_i32(c, c->d_found.p, 2 * np, SW_INF));
     CHIP(hipMemsetAsync(c->d_found64.p, 0xff, 2 * np * sizeof(u64), c->stream));
     CHIP(hipMemsetAsync(c->d_unres.p, 0, 2 * np * sizeof(int32_t), c->stream));
     CCHK(ensure_rounds(c, 256));
@@ -1827,7 +1824,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
-    dfree(c->d_pos_next); dfree(c->d_found); dfree(c->d_found64); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
     if (c->d_rb) (void)hipFree(c->d_rb);
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     if (c->h_fame) (void)hipHostFree(c->h_fame);
