@@ -19,6 +19,14 @@ of the kernels; GPU: two contexts on one device) and priced:
 `backend` objects need `decide_fame_partial(part, nparts) -> (famous int8 [R][n], decided uint8 [R])`
 and `commit_fame(famous, decided) -> new_c`: `engine.Hashgraph` on a GPU (RCCL), a numpy model in
 the CPU tests (gloo).
+
+Round 3 adds the split of the can_see TABLE by event ranges (`chunk_cuts`, `RowExchange`): what one
+GPU does with G concurrent chunks inside k_cansee_chunks, G ranks do with one chunk
+each — every rank sweeps its range from a halo before it with unknown parents as leaves, which needs
+NO communication; only entries whose ancestor is older than the halo are repaired from rows of lower
+ranks, fetched by `RowExchange` (none at uniform gossip with the default halo).  The sweep's depth
+and the table's memory divide by G; the round loop that follows stays one chain of dependent
+iterations (cost_model), so this partitions memory and the sweep, not the pass.
 """
 import numpy as np
 
@@ -59,10 +67,51 @@ class PartitionedFame:
         return backend.commit_fame(fam, dec)
 
 
-def cost_model(n=256, R=284, iterations=310, iter_us=25.0, sweep_ms=5.5, fame_ms=0.23, step_ms=9.9,
+def chunk_cuts(a0, b, parts):
+    """Event ranges [cuts[k], cuts[k+1]) of `parts` ranks over the events [a0, b)."""
+    return [a0 + (b - a0) * k // parts for k in range(parts + 1)]
+
+
+class RowExchange:
+    """Rows of a table partitioned by event ranges: every rank names the rows it needs from other ranks,
+    the owners answer.  Two collectives (requests, answers); object collectives here (gloo in the CPU
+    test) — on RCCL the same two steps are all_gathers of padded int32 tensors.  `bytes_moved` counts
+    the row payload received by this rank."""
+
+    def __init__(self, dist, rank, world, cuts):
+        self.dist, self.rank, self.world, self.cuts = dist, int(rank), int(world), list(cuts)
+        self.bytes_moved = 0
+
+    def owner(self, e):
+        for k in range(self.world):
+            if self.cuts[k] <= e < self.cuts[k + 1]:
+                return k
+        raise IndexError(e)
+
+    def fetch(self, events, local_rows):
+        """{event -> row} for `events` (owned by other ranks); `local_rows(e)` serves this rank's own rows to the
+        others.  Collective: every rank calls it, with an empty list when it needs nothing."""
+        want = sorted(set(int(e) for e in events))
+        all_want = [None] * self.world
+        self.dist.all_gather_object(all_want, want)
+        mine = {e: np.asarray(local_rows(e)) for w in all_want for e in w if self.owner(e) == self.rank}
+        all_rows = [None] * self.world
+        self.dist.all_gather_object(all_rows, mine)
+        got = {}
+        for k, rows in enumerate(all_rows):
+            if k == self.rank:
+                continue
+            for e, r in rows.items():
+                if e in want:
+                    got[e] = r
+                    self.bytes_moved += r.nbytes
+        return got
+
+
+def cost_model(n=256, R=284, iterations=310, iter_us=19.1, sweep_ms=3.1, fame_ms=0.23, step_ms=7.9,
                world=8, coll_us=20.0, link_GBps=50.0, links=7):
     """Back-of-envelope strong-scaling bound for ONE hashgraph over `world` GPUs of one node,
-    from this build's measured single-GPU numbers (defaults: 256 members / 1 M events, round 2).
+    from this build's measured single-GPU numbers (defaults: 256 members / 1 M events, round 3).
     coll_us = latency of one small RCCL collective over xGMI; link_GBps = effective per-link rate.
     Returns the modelled step time per variant (ms)."""
     out = {"single_gpu_ms": step_ms}
@@ -77,5 +126,15 @@ def cost_model(n=256, R=284, iterations=310, iter_us=25.0, sweep_ms=5.5, fame_ms
     #     all-gathered because every tally reads whole rows: N*n*4 bytes * (world-1)/world per rank
     gather_ms = (1_000_000 * n * 4) * (world - 1) / world / (links * link_GBps * 1e9) * 1e3
     out["can_see_sharded_ms"] = step_ms + gather_ms
-    out["best_speedup"] = step_ms / min(out["fame_partitioned_ms"], out["round_loop_partitioned_ms"], out["can_see_sharded_ms"])
+    # (4) the table split by EVENT RANGES (chunk_cuts / RowExchange; what k_cansee_chunks does with G chunks on
+    #     one GPU): every rank sweeps its range from a halo, no communication at uniform gossip, sweep
+    #     depth and memory / world.  The round loop stays ONE chain of dependent iterations: it runs rank
+    #     after rank (each over the rounds whose candidates it owns), handing over the loop state and the
+    #     rows of the last ~4 rounds of events (the band of the next rank's first tallies) — so the pass
+    #     saves at most what the single GPU still waits for its own sweep (~0.2 ms) and pays the hand-overs
+    band_rows_bytes = 4 * (1_000_000 // R) * n * 4
+    handover_ms = coll_us * 1e-3 + band_rows_bytes / (link_GBps * 1e9) * 1e3
+    out["can_see_event_ranges_ms"] = step_ms - 0.2 + (world - 1) * handover_ms
+    out["best_speedup"] = step_ms / min(out["fame_partitioned_ms"], out["round_loop_partitioned_ms"], out["can_see_sharded_ms"],
+                                        out["can_see_event_ranges_ms"])
     return out

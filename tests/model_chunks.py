@@ -78,10 +78,28 @@ def frontier(n, cr, w):
     return F
 
 
-def fixup(n, cr, L, a0, w, a, b):
-    """Repairs the provisional entries of the stored rows [a, b); rows below w must be final."""
+def fixup_needs(n, cr, L, a0, w, a, b, F=None):
+    """The events whose final rows the repair of the stored rows [a, b) reads (all below w)."""
+    if w <= a0:
+        return []
+    F = frontier(n, cr, w) if F is None else F
+    need = set()
+    for e in range(a, b):
+        V = L[e]
+        if (V < w).any():
+            E = np.where(V >= w, F, V.astype(np.int64))
+            need.update(int(x) for x in E[E >= a0])
+    return sorted(need)
+
+
+def fixup(n, cr, L, a0, w, a, b, rows=None):
+    """Repairs the provisional entries of the stored rows [a, b); rows below w must be final.  `rows(E)`
+    returns the final rows of the events E (default: this table — a rank of a partitioned table passes
+    the rows it fetched from the owners)."""
     if w <= a0:
         return 0
+    if rows is None:
+        rows = lambda E: L[E]
     F = frontier(n, cr, w)
     fixed = 0
     for e in range(a, b):
@@ -92,7 +110,7 @@ def fixup(n, cr, L, a0, w, a, b):
         E = np.where(V >= w, F, V.astype(np.int64))
         E = E[E >= a0]
         if len(E):
-            T = L[E][:, pcols].max(axis=0)
+            T = rows(E)[:, pcols].max(axis=0)
             new = np.maximum(V[pcols], T)
             fixed += int(np.count_nonzero(new != V[pcols]))
             L[e, pcols] = new
