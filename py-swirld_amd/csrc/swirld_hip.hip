@@ -173,7 +173,7 @@ struct sw_ctx {
 
     // tuning
     int skip = 1;         // SW_SKIP: window offset of a fresh round (0 = off); 1 measured best at 256 members (310 vs 326 iterations)
-    int gallop_after = 0; // strided candidate windows after this many windows without a passing candidate (0 = never)
+    int gallop_after = 2; // SW_GALLOP: strided candidate windows after this many windows without a passing candidate (0 = never); 2 costs uniform gossip nothing (the first window passes there) and cuts hot-member hashgraphs from 2756 to ~200 iterations
     int elect_impl = 1; // 1: NW threads per candidate where npad * NW <= 1024 (k_elections_split), 0: one thread per candidate
     int K = 28;        // candidates per member per tally launch: 7 waves per SIMD (the 8th slot is
                        // taken by the concurrent can_see sweep; 29+ costs a second wave generation)
