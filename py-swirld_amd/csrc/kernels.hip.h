@@ -931,7 +931,7 @@ template <int NW, int C, int F, int H, bool WIDE>
 __global__ void __launch_bounds__(64 * NW + 64)
 k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_start, const int* __restrict__ chain_ev,
                 const int* __restrict__ bnd, ChunkEv ce, int a0_all, int exact_chunk, int n_members,
-                int* L, int* halo, int halo_cap, unsigned* prov, unsigned gate_limit, int* err) {
+                int* L, int halo_row0, int halo_cap, unsigned* prov, unsigned gate_limit, int* err) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int npad = 64 * NW;
     constexpr int NT = npad;             // worker lanes = members
@@ -972,7 +972,9 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
     const int* pw = bnd + (size_t)(exact ? 2 * k + 1 : 2 * k) * npad;   // chain positions of the window start
     const int* pa = bnd + (size_t)(2 * k + 1) * npad;                   // ... of the first stored row
     const int* pe = bnd + (size_t)(2 * k + 3) * npad;                   // ... of the end of the chunk
-    int* const halo_k = halo + (size_t)k * halo_cap * npad;
+    // the scratch rows of the halo live in the SAME allocation as the table, behind its last row (one base
+    // pointer: a row select, global — not flat — stores, 32-bit offsets while the table stays below 4 GB)
+    const int halo_k0 = halo_row0 + k * halo_cap - w_k;   // halo event e -> row halo_k0 + e
     for (int i = tid; i < PL * npad * H; i += blockDim.x) ring[i] = make_int4(-1, -1, -1, -1);  // tag -1: empty
     for (int i = tid; i < npad; i += blockDim.x) { const int p = pw[i]; filled[i] = p; taken[i] = p; }
     __syncthreads();
@@ -1055,16 +1057,23 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
     bool have = false;
     unsigned n_prov = 0;
     const bool count_prov = !exact && w_k > a0;
-    // where the values of event e for my columns live: the table, or the scratch rows of the halo
-    // (w_k <= e < a_k).  Selects on integers, not branches on pointers.
-    const unsigned long long Lb = reinterpret_cast<unsigned long long>(L + col0);
-    const unsigned long long Hb = reinterpret_cast<unsigned long long>(halo_k + col0);
+    // F_c = the last event of member c before the window: the largest value column c can hold below w_k.  A
+    // computed value equal to it is FINAL although it lies outside the window (nothing of c in between can
+    // be missing) — what keeps the columns of members silent for longer than the halo from being provisional
+    // whenever a leaf (their newest event as somebody's other-parent) was reached.
+    int Fc[C], wthr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int pc = pw[col0 + c];
+        Fc[c] = (count_prov && pc > 0) ? chain_ev[chain_start[col0 + c] + pc - 1] : -1;
+        wthr[c] = col0 + c < n_members ? w_k : (int)0x80000000;   // padded columns are never provisional
+    }
+    // where the values of event e for my columns live: its row of the table, or a scratch row (w_k <= e < a_k)
+    char* const Lcol = reinterpret_cast<char*>(L + col0);
     auto row_ptr = [&](int e) -> int* {
-        const bool in_table = e >= a_k || e < a0;
-        const unsigned long long base = in_table ? Lb : Hb;
-        const unsigned row = (unsigned)(in_table ? e : e - w_k);
-        if (WIDE) return reinterpret_cast<int*>(base + (unsigned long long)row * (unsigned long long)(npad * 4));
-        return reinterpret_cast<int*>(base + (unsigned long long)(row * (unsigned)(npad * 4)));
+        const int row = ((e >= a_k) | (e < a0)) ? e : halo_k0 + e;
+        if (WIDE) return reinterpret_cast<int*>(Lcol + (size_t)row * (size_t)(npad * 4));
+        return reinterpret_cast<int*>(Lcol + (unsigned)row * (unsigned)(npad * 4));
     };
     if (p > 0 && p < pend) {
         // the member's last event before the window: a final row (zone i) or a leaf (zone ii)
@@ -1079,7 +1088,7 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
         }
     }
 #pragma unroll
-    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(mine[c]));  // the prologue loads are complete before the loop
+    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(mine[c]), "+v"(Fc[c]));  // the prologue loads are complete before the loop
     for (int spins = 0;; ++spins) {
         if (spins > SPIN_LIMIT) { if ((tid & 63) == 0) atomicExch(err, 1); break; }
         SW_CBAR();
@@ -1094,18 +1103,19 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
         int diff = 0;                    // every tag of every plane must be the wanted event
 #pragma unroll
         for (int h = 0; h < PL; ++h) diff |= (pr[h].y ^ o) | (pr[h].w ^ o);
-        const bool hit = diff == 0;      // (an event outside the window is never in the ring; a root polls nothing it uses)
+        // (bitwise operators on purpose: short-circuit ones become branches)
+        const bool hit = (mode == 0) & (diff == 0);   // (an event outside the window is never in the ring)
         int other[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int rv = (c & 1) ? pr[c >> 1].z : pr[c >> 1].x;
-            other[c] = mode == 0 ? (hit ? rv : -1) : oth[c];
+            other[c] = hit ? rv : oth[c];            // (oth is -1 in every column while the ring is polled)
         }
-        bool ready = have && (mode == 2 || (mode == 0 && hit));
+        bool ready = have & ((mode == 2) | hit);
         // rare: the other-parent's row comes from memory (a final row of an earlier launch, or a ring slot
         // that was reused — plane 0 is written first, so its tag is the newest: the row, real or halo, is
         // then >= H store instructions old)
-        const bool from_mem = have && !ready && (mode == 1 || pr[0].y > o);
+        const bool from_mem = have & !ready & ((mode == 1) | (pr[0].y > o));
         if (__ballot(from_mem)) {
             if (from_mem) {
                 load_cols_sc1_and_wait<C>(row_ptr(o), other);
@@ -1130,10 +1140,10 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
 #pragma unroll
             for (int h = 0; h < PL; ++h) ring[(size_t)h * H * npad + slot] = make_int4(v[2 * h], e, v[2 * h + 1], e);
             if (count_prov) {   // a stored row of a chunk with unknown parents: count the stores that hold something to repair
-                int vmin = 0x7fffffff;
+                int pv = 0;   // (bitwise on purpose: short-circuit operators become branches in this loop)
 #pragma unroll
-                for (int c = 0; c < C; ++c) if (col0 + c < n_members) vmin = v[c] < vmin ? v[c] : vmin;
-                n_prov += (e >= a_k && vmin < w_k) ? 1u : 0u;
+                for (int c = 0; c < C; ++c) pv |= (int)(v[c] < wthr[c]) & (int)(v[c] != Fc[c]);
+                n_prov += (unsigned)(pv & (int)(e >= a_k));
             }
             ++p;
             have = false;
@@ -1197,7 +1207,7 @@ k_cansee_fixup(const int* __restrict__ chain_start, const int* __restrict__ chai
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             V[j] = L[(size_t)e * npad + j * 64 + lane];
-            pm[j] = __ballot(V[j] < w && j * 64 + lane < n_members);
+            pm[j] = __ballot(V[j] < w && V[j] != s_F[j * 64 + lane] && j * 64 + lane < n_members);   // (== F_c: final, see the sweep)
             any = any || pm[j] != 0;
             E[j] = V[j] >= w ? s_F[j * 64 + lane] : V[j];
             if (E[j] < a0) E[j] = -1;

@@ -109,7 +109,6 @@ struct sw_ctx {
     // {w_0, a_0, w_1, a_1, ..., end, end}, the halo rows' scratch table, provisional-entry counters (inside d_rb)
     DBuf<int32_t> d_cbnd;
     DBuf<long long> d_ccuts;
-    DBuf<int32_t> d_halo;
     unsigned* d_prov = nullptr;   // [SW_PROV_ROWS][SW_MAX_CHUNKS] provisional entries per chunk, then [SW_PROV_ROWS] repaired entries
     int chunks = 4;               // SW_CHUNKS: chunks swept concurrently per sub-batch (1 = the unchunked k_cansee_flow)
     int chunk_cfg = 0;            // SW_CHUNK_CFG: 0 = 4 columns per lane, FIFO 8, ring 8; 1 = 2 columns, 8 / 16; 2 = 4 columns, 4 / 8
@@ -386,7 +385,9 @@ int ensure_events(sw_ctx* c, int64_t need) {
     CHK(dgrow(c, c->d_t, nc, keep));
     CHK(dgrow(c, c->d_sig, (size_t)nc * 64, keep * 64));
     CHK(dgrow(c, c->d_S, (size_t)nc * c->nw, keep * c->nw));
-    if (!c->vm.active) CHK(dgrow(c, c->d_L, (size_t)nc * c->npad, keep * c->npad));  // (windowed table: chunks are mapped per append)
+    // (windowed table: chunks are mapped per append.)  Behind the last row: the scratch rows of the chunk-parallel
+    // sweep's halos (k_cansee_chunks), SW_MAX_CHUNKS x halo rows
+    if (!c->vm.active) CHK(dgrow(c, c->d_L, (size_t)(nc + (c->npad <= 256 ? SW_MAX_CHUNKS * c->halo : 0)) * c->npad, keep * c->npad));
     c->cap = nc;
     return SW_OK;
 }
@@ -672,7 +673,7 @@ int launch_cansee_chunks_t(sw_ctx* c, int i) {
     constexpr int NCG = npad / C;
     const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
     const size_t lds = (size_t)npad * ((size_t)F * 16 + (size_t)(C / 2) * H * 16 + 8);
-    const bool wide = (size_t)c->cap * (size_t)npad * sizeof(int32_t) >= (1ull << 32);
+    const bool wide = ((size_t)c->cap + (size_t)SW_MAX_CHUNKS * (size_t)c->halo) * (size_t)npad * sizeof(int32_t) >= (1ull << 32);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k_cansee_chunks<NW, C, F, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
@@ -689,11 +690,11 @@ int launch_cansee_chunks_t(sw_ctx* c, int i) {
         if (wide)
             hipLaunchKernelGGL((k_cansee_chunks<NW, C, F, H, true>), dim3(grid), dim3(npad + 64), lds, cs,
                                (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, bnd, ce,
-                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, c->d_halo.p, (int)c->halo, prov, limit, c->d_flow_err);
+                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, (int)c->cap, (int)c->halo, prov, limit, c->d_flow_err);
         else
             hipLaunchKernelGGL((k_cansee_chunks<NW, C, F, H, false>), dim3(grid), dim3(npad + 64), lds, cs,
                                (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, bnd, ce,
-                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, c->d_halo.p, (int)c->halo, prov, limit, c->d_flow_err);
+                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, (int)c->cap, (int)c->halo, prov, limit, c->d_flow_err);
         c->ctr.kernel_launches++;
     };
     sweep(pl.G * NCG, -1, 0u);
@@ -1077,7 +1078,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     // ---- chunk plan: a sub-batch long enough is cut into G chunks that are swept concurrently, each from
     // `halo` events before its start (k_cansee_chunks); their chain positions come from one more search kernel
     c->chunk_plan.assign(S, sw_ctx::ChunkPlan{});
-    if (flow && np <= 256 && c->chunks > 1 && !c->chunks_off && S <= SW_PROV_ROWS) {
+    if (flow && np <= 256 && c->chunks > 1 && !c->chunks_off && !c->vm.active && S <= SW_PROV_ROWS) {
         std::vector<long long>& ccuts = c->ccuts_stage;
         ccuts.clear();
         int max_g = 0;
@@ -1101,7 +1102,6 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         if (!ccuts.empty()) {
             CHK(dgrow(c, c->d_ccuts, ccuts.size(), 0));
             CHK(dgrow(c, c->d_cbnd, ccuts.size() * (size_t)np, 0));
-            CHK(dgrow(c, c->d_halo, (size_t)max_g * (size_t)std::max<int64_t>(c->halo, 1) * np, 0));
             // (pageable source: the copy is staged before the call returns)
             HIPCHK(c, hipMemcpyAsync(c->d_ccuts.p, ccuts.data(), ccuts.size() * sizeof(long long), hipMemcpyHostToDevice, cs));
             hipLaunchKernelGGL(k_chain_bounds, dim3((unsigned)ccuts.size()), dim3(np), 0, cs, (const int*)c->d_chain_start.p,

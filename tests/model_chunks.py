@@ -13,9 +13,11 @@ Zones of a parent x of an event of chunk k (window start w_k = max(a_0, a_k - ha
   (ii)  a_0 <= x < w_k   rows another chunk is computing right now: UNKNOWN.  x is treated as a
         LEAF: the row {creator(x): x}, everything else absent;
   (iii) x >= w_k  inside the window: computed by this chunk (halo rows are recomputed, not stored).
-A value v = V[e][c] of the local sweep is FINAL iff v >= w_k: an ancestor by c inside the window
+A value v = V[e][c] of the local sweep is FINAL if v >= w_k: an ancestor by c inside the window
 exists, every path to an in-window ancestor stays inside the window (ancestors have smaller
-indices), so the local maximum is the true one.  Otherwise it is PROVISIONAL and
+indices), so the local maximum is the true one.  It is also final if v == F_c, the last event of c
+before w_k: no larger value below w_k exists (what settles the columns of members silent for longer
+than the halo as soon as their newest event was reached as a leaf).  Otherwise it is PROVISIONAL and
     T[e][c] = max(V[e][c], max over members m with a zone-(ii) entry of T[E_m(e)][c]),
     E_m(e) = F_m = last event of m before w_k   if V[e][m] >= w_k  (e reaches m's chain inside the
                                                   window, hence F_m through self-parents)
@@ -46,6 +48,7 @@ def local_sweep(n, cr, sp, op, L, a0, w, a, b):
     """Rows of the window [w, b) with zone-(ii) parents as leaves; rows of [a, b) are stored into L
     (halo rows [w, a) live in a scratch table).  Returns the number of provisional entries stored."""
     halo = {}
+    F = frontier(n, cr, w) if w > a0 else None
 
     def row_of(x):
         if x < a0:
@@ -66,7 +69,7 @@ def local_sweep(n, cr, sp, op, L, a0, w, a, b):
         else:
             L[e] = r
             if w > a0:
-                prov += int(np.count_nonzero(r < w))
+                prov += int(np.count_nonzero((r < w) & (r != F)))
     return prov
 
 
@@ -86,7 +89,7 @@ def fixup_needs(n, cr, L, a0, w, a, b, F=None):
     need = set()
     for e in range(a, b):
         V = L[e]
-        if (V < w).any():
+        if ((V < w) & (V != F)).any():
             E = np.where(V >= w, F, V.astype(np.int64))
             need.update(int(x) for x in E[E >= a0])
     return sorted(need)
@@ -104,7 +107,7 @@ def fixup(n, cr, L, a0, w, a, b, rows=None):
     fixed = 0
     for e in range(a, b):
         V = L[e]
-        pcols = np.nonzero(V < w)[0]
+        pcols = np.nonzero((V < w) & (V != F))[0]
         if not len(pcols):
             continue
         E = np.where(V >= w, F, V.astype(np.int64))

@@ -82,14 +82,14 @@ def test_ample_halo_leaves_nothing_to_repair_at_uniform_gossip(pkg, monkeypatch)
     h.close()
 
 
-def test_silent_members_switch_the_context_back_to_the_unchunked_sweep(pkg, monkeypatch):
-    """Members silent for longer than the halo leave whole columns provisional: the chunks are swept a second
-    time from final rows (exact), and the context stops chunking for the calls that follow."""
+def test_too_many_provisional_entries_switch_the_context_back_to_the_unchunked_sweep(pkg, monkeypatch):
+    """Without a halo every chunk starts with thousands of provisional stores: beyond the limit the chunks are
+    swept a second time from final rows (exact), and the context stops chunking for the calls that follow."""
     from oracle.oracle import Oracle
     monkeypatch.setenv("SW_CHUNK_MIN", "2048")
-    monkeypatch.setenv("SW_HALO", "512")
+    monkeypatch.setenv("SW_HALO", "0")
     n, N = 64, 40000
-    stream = pkg.synth_hashgraph(n, N, 31, 2, 0.5, 2000.0)   # half of the members 2000x less active
+    stream = pkg.synth_hashgraph(n, N, 31)
     o, h = Oracle(n), pkg.Hashgraph(n)
     half = N // 2
     for a, b in ((0, half), (half, N)):
@@ -103,4 +103,24 @@ def test_silent_members_switch_the_context_back_to_the_unchunked_sweep(pkg, monk
     assert c["chunk_sweeps"] == first["chunk_sweeps"], (first, c)     # the second call ran unchunked
     assert np.array_equal(h.can_see(), o.can_see)
     assert np.array_equal(h.rounds(), o.round)
+    h.close()
+
+
+def test_silent_members_are_settled_by_their_frontier_event(pkg, monkeypatch):
+    """Members silent for longer than the halo: their columns hold the member's newest event (reached as a
+    leaf, or through final rows), which is final although it lies outside the window — so such hashgraphs keep
+    the chunk-parallel sweep, with a handful of repairs instead of second sweeps."""
+    from oracle.oracle import Oracle
+    monkeypatch.setenv("SW_CHUNK_MIN", "2048")
+    monkeypatch.setenv("SW_HALO", "1024")
+    n, N = 64, 40000
+    stream = pkg.synth_hashgraph(n, N, 31, 2, 0.5, 2000.0)   # half of the members 2000x less active than the others
+    o, h = Oracle(n), pkg.Hashgraph(n)
+    for d in (o, h):
+        d.append_events(*stream)
+        d.divide_rounds(0, N)
+    assert np.array_equal(h.can_see(), o.can_see)
+    assert np.array_equal(h.rounds(), o.round)
+    c = h.counters()
+    assert c["chunk_sweeps"] >= 4 and c["chunk_resweeps"] == 0, c
     h.close()
