@@ -1823,27 +1823,29 @@ k_tally_candidates(LoopBufs B, int par, int K,
                    const int* __restrict__ op, const u64* __restrict__ Mb,
                    const uint32_t* __restrict__ stake, uint32_t tot2, int npad) {
     __shared__ u64 s_hm[4][NW * 64];
+    __shared__ u64 s_key[4];
+    __shared__ int s_fark[4], s_cm[4];
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
     const int* unres = B.unres + pb;
     const int* lo_r = B.lo_r + pb;
-    if (st->done) return;
+    if (st->done) return;   // (uniform over the grid)
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
     const int w = blockIdx.x * 4 + wib;
     const int cm = w / K, cj = w - cm * K;  // member, candidate slot
-    if (!unres[cm]) return;
-    const int e = B.cand[((size_t)(1 - par) * npad + cm) * 64 + cj + 1];  // slot cj of the member's window
-    if (e < 0) return;
+    // verdicts reduced per workgroup before the atomics, as in k_tally_bits
+    u64 key = ~0ull;
+    int fark = SW_INF;
+    u64 nfar = 0;
+    const int e = unres[cm] ? B.cand[((size_t)(1 - par) * npad + cm) * 64 + cj + 1] : -1;  // slot cj of the member's window
+    if (e >= 0) do {
     const int mlo = st->mlo, mhi = st->mhi;
     u64* hm = s_hm[wib];
     const int ce = cr[e], spe = sp[e];
     {   // FAR candidate (a parent beyond the band): decided by inheritance in k_resolve_band
         const int ope = op[e];
-        if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && B.force[pb + cm])) {
-            if (lane == 0) atomicMin(&B.farslot[pb + cm], cj);
-            return;
-        }
+        if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && B.force[pb + cm])) { fark = cj; break; }
     }
     int thr[NW];
     int P[NW];
@@ -1856,7 +1858,6 @@ k_tally_candidates(LoopBufs B, int par, int K,
         P[j] = v;
         hits[j] = 0;
     }
-    u64 nfar = 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int k = P[j];
@@ -1889,10 +1890,20 @@ k_tally_candidates(LoopBufs B, int par, int K,
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(3u * hits[j] > tot2));
+    if (3u * cnt > tot2)  // count of members vs the STAKE threshold (Q2)
+        key = ((u64)(uint32_t)e << 32) | ((u64)cj << 26) | 0x3ffffffull;
+    } while (0);
+    if (lane == 0) { s_key[wib] = key; s_fark[wib] = fark; s_cm[wib] = cm; }
+    __syncthreads();
     if (lane == 0) {
-        if (3u * cnt > tot2)  // count of members vs the STAKE threshold (Q2)
-            atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]),
-                      ((u64)(uint32_t)e << 32) | ((u64)cj << 26) | 0x3ffffffull);
+        if (wib == 0 || s_cm[wib - 1] != cm) {   // the first wave of a member in this workgroup speaks for the member's waves
+            for (int w2 = wib + 1; w2 < 4 && s_cm[w2] == cm; ++w2) {
+                key = s_key[w2] < key ? s_key[w2] : key;
+                fark = s_fark[w2] < fark ? s_fark[w2] : fark;
+            }
+            if (key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]), key);
+            if (fark != SW_INF) atomicMin(&B.farslot[pb + cm], fark);
+        }
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
 }

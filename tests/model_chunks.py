@@ -121,22 +121,24 @@ def fixup(n, cr, L, a0, w, a, b, rows=None):
 
 
 def cansee_chunked(n, cr, sp, op, a0, cuts, halo, L=None, resweep_limit=None):
-    """can_see rows of the events [a0, cuts[-1]) given the final rows below a0 (in L), by chunks
-    [cuts[k], cuts[k+1]) with cuts[0] == a0.  Every local sweep only reads zone-(i) rows and its own
-    window, so the G sweeps are independent (the loop below could run them in any order or
-    concurrently); the repairs run in ascending chunk order.  `resweep_limit`: a chunk with more
-    provisional entries than this is swept again sequentially instead of repaired entry by entry
-    (what the device does when gathers would cost more than the dependent sweep).
-    Returns (L, stats)."""
+    """can_see rows of the events [cuts[0], cuts[-1]) by chunks [cuts[k], cuts[k+1]), given the final
+    rows below cuts[0] (in L).  Rows below a0 are READ by the sweeps (zone i); rows in [a0, cuts[0]) are
+    final too but the sweeps treat them as unknown (leaves) and only the repairs read them — a0 = 0 is
+    what the device does (no sweep ever reads a row from memory: chunk 0 gets a halo like the others).
+    Every local sweep only reads zone-(i) rows and its own window, so the G sweeps are independent (the
+    loop below could run them in any order or concurrently); the repairs run in ascending chunk order.
+    `resweep_limit`: a chunk with more provisional entries than this is swept again sequentially
+    instead of repaired entry by entry (what the device does when gathers would cost more than the
+    dependent sweep).  Returns (L, stats)."""
     N = len(cr)
-    assert cuts[0] == a0 and all(x < y for x, y in zip(cuts, cuts[1:])) and cuts[-1] <= N
+    assert cuts[0] >= a0 and all(x < y for x, y in zip(cuts, cuts[1:])) and cuts[-1] <= N
     if L is None:
         L = np.full((N, n), -1, np.int32)
     stats = dict(prov=[], fixed=[], resweeps=0, halo_events=0)
     windows = []
     for k in range(len(cuts) - 1):
         a, b = cuts[k], cuts[k + 1]
-        w = max(a0, a - halo) if k else a0
+        w = max(a0, a - halo)
         windows.append((w, a, b))
     for w, a, b in reversed(windows):            # any order: the sweeps do not depend on each other
         stats["prov"].insert(0, local_sweep(n, cr, sp, op, L, a0, w, a, b))

@@ -38,6 +38,12 @@ def test_chunked_rows_equal_sequential_rows(n, N, seed, mode, p0, p1):
                 L[:a0] = ref[:a0]
                 L, st2 = cansee_chunked(n, cr, sp, op, a0, cuts, halo, L, resweep_limit=n)
                 assert np.array_equal(L, ref), (halo, G, a0, cuts, st2)
+                # the device's form: no sweep reads a row from memory (leaf boundary 0), the first chunk has a
+                # halo like the others, the final rows below the range only serve the repairs
+                L = np.full((N, n), -1, np.int32)
+                L[:a0] = ref[:a0]
+                L, st3 = cansee_chunked(n, cr, sp, op, 0, cuts, halo, L)
+                assert np.array_equal(L, ref), (halo, G, a0, cuts, st3)
 
 
 def test_uniform_gossip_needs_no_repair_with_an_ample_halo():
