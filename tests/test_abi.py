@@ -98,7 +98,7 @@ def test_committed_measurement_fixtures_bench_reads():
     from conftest import ROOT
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         tr = json.load(f)
-    assert tr["commit"] and tr["kernels"]["k_cansee_flow"] > 0
+    assert tr["commit"] and tr["kernels"]["k_cansee_chunks"] > 0 and tr["kernels"]["k_tally_bits"] > 0
     with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
         rp = json.load(f)
     assert rp["reference_equals_oracle_on_this_prefix"] is True and rp["members"] == 256 and rp["events_per_s"] > 0
