@@ -1328,6 +1328,9 @@ struct LoopBufs {
     int* lo_r;        // [2][npad] thresholds of the round being resolved
     int* cur;         // [2][npad] chain position of the member's next candidate window
     int* unres;       // [2][npad] member still searching its first round-(r+1) event
+    int* nx1;         // [2][npad] lo[r+1][c], lo[r+2][c], lopos[r+1][c] for the round r of this state buffer, as they stood
+    int* nx2;         //           when the writer block stored the state (rows of EARLIER calls: INF in a batch run):
+    int* nxp1;        //           handed over with the state instead of being looked up behind `r` (a dependent round trip)
     int* lo_next;     // [2][npad] lo[r+1][c] found so far in this round
     int* pos_next;    // [2][npad] ... and its chain position
     int* evalround;   // [2][npad] round in which the member's chain was last exhausted
@@ -1406,7 +1409,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     __shared__ int s_ce[1024];    // chain_ev index one past b's last visible event
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.lo_next); pin_arg(B.pos_next);
-    pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found64); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
+    pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.nx1); pin_arg(B.nx2); pin_arg(B.nxp1); pin_arg(B.found64); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
     pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
     pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
@@ -1434,6 +1437,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     int frc = member ? B.force[in + c] : 0;
     const int gsv = member ? B.gallop[in + c] : 1;
     int evr_now = member ? B.evalround[in + c] : -1, evp_now = member ? B.evalpos[in + c] : 0;
+    const int in_nx1 = member ? B.nx1[in + c] : SW_INF, in_nx2 = member ? B.nx2[in + c] : SW_INF;
+    const int in_nxp1 = member ? B.nxp1[in + c] : 0;
     const int in_lo_next = member ? B.lo_next[in + c] : SW_INF;
     const int in_pos_next = member ? B.pos_next[in + c] : 0;
     int thr = member ? B.lo_r[in + c] : SW_INF;
@@ -1445,9 +1450,14 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         if (writer && c == 0) *so = *si;
         return;
     }
-    const int lo_r1 = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
-    const int lo_r2 = (member && r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
-    const int lopos_r1 = (member && r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
+    // lo[r+1], lo[r+2], lopos[r+1]: handed over by the writer block of the previous iteration (first round trip);
+    // the first iteration of a run looks them up (`iter` is uniform: a scalar branch)
+    int lo_r1 = in_nx1, lo_r2 = in_nx2, lopos_r1 = in_nxp1;
+    if (iter == 0) {
+        lo_r1 = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
+        lo_r2 = (member && r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
+        lopos_r1 = (member && r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
+    }
     int my_lo_next = iter > 0 ? in_lo_next : SW_INF;
     int my_pos_next = iter > 0 ? in_pos_next : 0;
     int mlo = s_mlo, mhi = s_mhi;
@@ -1676,7 +1686,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // Entries 1 .. K are the candidates; a contiguous window is published up to 63 positions far (never tallied:
     // the tally of slot j hands entry j + skip + K — the last candidate of the window that would follow slot
     // j — on to the next resolve step together with its verdict).
-    const int KPS = 64;
+    const int KPS = (NW <= 4 || K >= 32) ? 64 : 32;   // (wider member counts: no look-ahead — their iterations are throughput-bound)
     int cand_v = -1;
     const bool cand_mine = (int)blockIdx.x < npad && (int)threadIdx.x < KPS;
     {
@@ -1724,6 +1734,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             B.farslot[out + c] = SW_INF;
             B.force[out + c] = frc;
             B.gallop[out + c] = strd | (miss << 8) | (skp << 16);
+            // the rows the next iteration will want behind its round (never the row committed above: that is lo[r])
+            B.nx1[out + c] = r + 1 < Rcap ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
+            B.nx2[out + c] = r + 2 < Rcap ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
+            B.nxp1[out + c] = r + 1 < Rcap ? lopos[(size_t)(r + 1) * npad + c] : 0;
         }
         if (c == 0) {
             RState t = *si;
@@ -2158,7 +2172,8 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     // what the next resolve step will want if this slot is the member's first passing one: the last candidate of
     // the window that would follow it (entry j + skip + K of a contiguous window's look-ahead; -1: not published)
     const int la_i = cj + skip + K;
-    const int la = la_i < 64 ? cand[la_i < 64 ? la_i : 63] : -1;
+    const bool use_la = NW <= 4 || K >= 32;   // (the table is published 63 positions far only then, see k_resolve_band)
+    const int la = (use_la && la_i < 64) ? cand[(use_la && la_i < 64) ? la_i : 0] : -1;
     const int gsv = B.gallop[pb + cm];
     int thr[NW], P[NW];
 #pragma unroll
@@ -2681,6 +2696,169 @@ k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const
         if (tid == 0) {
             u64 tot = 0, totv = 0, totf = 0;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot += s_p2[w]; totv += s_cv[w]; totf += s_cf[w]; }
+            if (tot) atomicAdd(&fc->majority_evals, tot);
+            if (totv) atomicAdd(&fc->coin_votes, totv);
+            if (totf) atomicAdd(&fc->coin_flips, totf);
+        }
+    }
+}
+
+// ... and for member counts beyond 256 (npad * NW > 1024 threads): the candidates of a round are split over
+// npad / CG workgroups of CG = 1024 / NW candidates x NW threads.  The voters' masks are read from global memory
+// (a round of them is 128 KB at 1024 members: no LDS staging; the word a wave reads is the same for all its
+// lanes), the per-level exchange stays in LDS, and what concerns the ROUND — "every witness decided, at least one
+// of them in this call" (swirld.py:274-277) — is agreed through three words per round in `rsc` (zeroed by the
+// host): open witnesses, decided flag, arrival ticket; the last workgroup of the round to arrive publishes it.
+// One thread per candidate (k_elections) took 6.7 ms per pass at 1024 members / 2 M events.
+template <int NW, bool UNIT>
+__global__ void __launch_bounds__(1024)
+k_elections_wide(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsigned char* __restrict__ coin,
+                 const uint32_t* __restrict__ stake, uint32_t tot2, int coin_period, int max_c, int R,
+                 int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc, int* dec_call, int* dec_by,
+                 int call_idx, int part, int nparts, int* rsc) {
+    constexpr int CG = 1024 / NW;          // candidates per workgroup
+    const int GB = npad / CG;              // workgroups per round
+    const int rb = (int)blockIdx.x / GB, g = (int)blockIdx.x - rb * GB;
+    const int r = max_c + part + nparts * rb;
+    const int tid = threadIdx.x;
+    const int j = tid / CG, cxl = tid - j * CG;   // CG is a multiple of 64: j is uniform in a wave
+    const int cx = g * CG + cxl;
+    const int x = wit[(size_t)r * npad + cx];
+    {
+        const int nw_r = __syncthreads_count(j == 0 && x >= 0);
+        if (tid == 0 && r > max_c && nw_r) atomicAdd(&fc->voter_evals, (u64)nw_r);
+    }
+    if (cons[r]) return;
+    __shared__ int s_wv[64 * NW];
+    __shared__ u64 s_V[NW][CG];
+    __shared__ int s_bi[NW][CG];
+    __shared__ int s_bv[NW][CG];
+    __shared__ int s_nv[NW];
+    __shared__ u64 s_p2[16], s_cv[16], s_cf[16];
+    bool active = x >= 0 && fam[(size_t)r * npad + cx] < 0;
+    u64 V[NW];
+#pragma unroll
+    for (int jj = 0; jj < NW; ++jj) V[jj] = 0;
+    int any_decided = 0;
+    u64 p2 = 0, cvotes = 0, cflips = 0;
+    for (int d = 1; r + d < R; ++d) {
+        if (!__syncthreads_or(active)) break;  // also: every read of the previous level is done
+        const int rv = r + d;
+        const int* wv_row = wit + (size_t)rv * npad;
+        const u64* sw_row = Sw + (size_t)rv * npad * NW;
+        const bool coin_round = (d % coin_period) == 0;
+        for (int i = tid; i < npad; i += 1024) s_wv[i] = wv_row[i];
+        __syncthreads();
+        u64 acc = 0;
+        int best_idx = SW_INF, best_v = 0, nv = 0;
+        for (int ci = 0; ci < 64; ++ci) {
+            const int c = j * 64 + ci;
+            const int wv = s_wv[c];  // uniform in the wave
+            if (wv < 0) continue;
+            ++nv;
+            const u64* m = sw_row + (size_t)c * NW;   // (the same words for every lane of the wave)
+            int bitv;
+            if (d == 1) {
+                bitv = (int)((m[cx >> 6] >> (cx & 63)) & 1ull);  // x in s (swirld.py:258)
+            } else {
+                uint32_t yes = 0, tot = 0;
+                if (UNIT) {
+#pragma unroll
+                    for (int jj = 0; jj < NW; ++jj) {
+                        const u64 mm = m[jj];
+                        yes += __popcll(mm & V[jj]);
+                        tot += __popcll(mm);
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < NW; ++jj) {
+                        u64 mm = m[jj];
+                        while (mm) {
+                            const int b = __ffsll((long long)mm) - 1;
+                            mm &= mm - 1;
+                            const uint32_t sk = stake[jj * 64 + b];
+                            tot += sk;
+                            if ((V[jj] >> b) & 1ull) yes += sk;
+                        }
+                    }
+                }
+                const uint32_t no = tot - yes;
+                const int v = !(no > yes);  // majority(): tie -> True (swirld.py:24-27)
+                const uint32_t t = v ? yes : no;
+                const bool sm = 3u * t > tot2;
+                if (!coin_round) {
+                    if (sm && wv < best_idx) { best_idx = wv; best_v = v; }
+                    bitv = v;
+                } else {
+                    bitv = sm ? v : (int)coin[wv];  // swirld.py:267-272
+                    if (active) { ++cvotes; cflips += !sm; }
+                }
+            }
+            acc |= (u64)bitv << ci;
+        }
+        s_V[j][cxl] = acc;
+        s_bi[j][cxl] = best_idx;
+        s_bv[j][cxl] = best_v;
+        if (cxl == 0) s_nv[j] = nv;
+        __syncthreads();
+        int nvoters = 0;
+        best_idx = SW_INF;
+        best_v = 0;
+#pragma unroll
+        for (int jj = 0; jj < NW; ++jj) {
+            V[jj] = s_V[jj][cxl];
+            nvoters += s_nv[jj];
+            const int bi = s_bi[jj][cxl];
+            if (bi < best_idx) { best_idx = bi; best_v = s_bv[jj][cxl]; }
+        }
+        if (active && d >= 2) {
+            if (!coin_round && best_idx != SW_INF) {
+                active = false;
+                any_decided = 1;
+                if (j == 0) {
+                    fam[(size_t)r * npad + cx] = (signed char)best_v;  // swirld.py:263
+                    dec_call[(size_t)r * npad + cx] = call_idx;        // which decide_fame() call decided x, and which voter
+                    dec_by[(size_t)r * npad + cx] = best_idx;
+                    int le = 0;  // voters after the first decider never evaluate x
+                    for (int c = 0; c < npad; ++c) {
+                        const int wv = s_wv[c];
+                        le += (wv >= 0 && wv <= best_idx);
+                    }
+                    p2 += le;
+                }
+            } else if (j == 0) {
+                p2 += nvoters;
+            }
+        }
+    }
+    const int x_open = j == 0 && x >= 0 && active;   // (`active` mirrors fam < 0 for this thread's candidate)
+    const int n_open = __syncthreads_count(x_open);
+    const int dec = __syncthreads_or(any_decided);
+    if (tid == 0) {  // swirld.py:274-277, over the workgroups of the round
+        if (n_open) atomicAdd(&rsc[3 * r], n_open);
+        if (dec) atomicOr(&rsc[3 * r + 1], 1);
+        __threadfence();
+        if (atomicAdd(&rsc[3 * r + 2], 1) == GB - 1) {
+            __threadfence();
+            if (atomicAdd(&rsc[3 * r], 0) == 0 && atomicAdd(&rsc[3 * r + 1], 0) != 0) {
+                newc[r] = 1;
+                cons[r] = 1;
+            }
+        }
+    }
+    {   // one atomic per workgroup and counter
+        u64 t = p2, tv = cvotes, tf = cflips;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            t += (u64)__shfl_xor((long long)t, off);
+            tv += (u64)__shfl_xor((long long)tv, off);
+            tf += (u64)__shfl_xor((long long)tf, off);
+        }
+        if ((tid & 63) == 0) { s_p2[tid >> 6] = t; s_cv[tid >> 6] = tv; s_cf[tid >> 6] = tf; }
+        __syncthreads();
+        if (tid == 0) {
+            u64 tot = 0, totv = 0, totf = 0;
+            for (int w = 0; w < 16; ++w) { tot += s_p2[w]; totv += s_cv[w]; totf += s_cf[w]; }
             if (tot) atomicAdd(&fc->majority_evals, tot);
             if (totv) atomicAdd(&fc->coin_votes, totv);
             if (totf) atomicAdd(&fc->coin_flips, totf);

@@ -152,8 +152,9 @@ struct sw_ctx {
     hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr;
     std::vector<int32_t> divided_cnt;   // per member: events already divided (chain positions below `divided`)
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
-    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_farslot, d_force, d_cand, d_gallop;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_nx1, d_nx2, d_nxp1, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
+    DBuf<int32_t> d_rsc;   // [R][3] round-level agreement of k_elections_wide: open witnesses, decided flag, arrival ticket
     DBuf<u64> d_found64;   // [2][npad] {event << 32 | slot << 26 | look-ahead} of the members' first passing candidates (LoopBufs::found64)
     // one device block read back with ONE copy per round-loop shot: loop state (x2), sweep error flag, per-member
     // front rounds; and its pinned host mirror
@@ -759,6 +760,7 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.lo_r = c->d_lo_r.p; B.cur = c->d_cur.p; B.unres = c->d_unres.p; B.lo_next = c->d_lo_next.p;
     B.pos_next = c->d_pos_next.p; B.evalround = c->d_evalround.p; B.evalpos = c->d_evalpos.p;
     B.found64 = c->d_found64.p;
+    B.nx1 = c->d_nx1.p; B.nx2 = c->d_nx2.p; B.nxp1 = c->d_nxp1.p;
     B.farslot = c->d_farslot.p;
     B.force = c->d_force.p;
     B.cand = c->d_cand.p;
@@ -1302,6 +1304,16 @@ int fame_launch(sw_ctx* c, int max_c, int part, int nparts, Span* sp_el) {
                 split_done = true;
             }
         }
+        if constexpr (NW >= 8) {  // beyond 256 members: the candidates of a round over npad * NW / 1024 workgroups (k_elections_wide)
+            if (c->elect_impl == 1) {
+                CHK(dgrow(c, c->d_rsc, (size_t)3 * c->Rcap, 0));
+                HIPCHK(c, hipMemsetAsync(c->d_rsc.p, 0, (size_t)3 * R * sizeof(int32_t), c->stream));
+                const int gb = np * NW / 1024;
+                if (c->unit_stake) hipLaunchKernelGGL((k_elections_wide<NW, true>), dim3(nblk * gb), dim3(1024), 0, c->stream, SW_ELECT_ARGS, c->d_rsc.p);
+                else hipLaunchKernelGGL((k_elections_wide<NW, false>), dim3(nblk * gb), dim3(1024), 0, c->stream, SW_ELECT_ARGS, c->d_rsc.p);
+                split_done = true;
+            }
+        }
         if (!split_done) {
             if (c->unit_stake) hipLaunchKernelGGL((k_elections<NW, true>), dim3(nblk), dim3(np), 0, c->stream, SW_ELECT_ARGS);
             else hipLaunchKernelGGL((k_elections<NW, false>), dim3(nblk), dim3(np), 0, c->stream, SW_ELECT_ARGS);
@@ -1753,6 +1765,9 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_lo_next, 2 * np, 0));
     CCHK(dgrow(c, c->d_pos_next, 2 * np, 0));
     CCHK(dgrow(c, c->d_found64, 2 * np, 0));
+    CCHK(dgrow(c, c->d_nx1, 2 * np, 0));
+    CCHK(dgrow(c, c->d_nx2, 2 * np, 0));
+    CCHK(dgrow(c, c->d_nxp1, 2 * np, 0));
     CCHK(dgrow(c, c->d_farslot, 2 * np, 0));
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
     CCHK(dgrow(c, c->d_cand, (size_t)2 * np * 64, 0));
@@ -1824,7 +1839,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
-    dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_rsc); dfree(c->d_nx1); dfree(c->d_nx2); dfree(c->d_nxp1); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
     if (c->d_rb) (void)hipFree(c->d_rb);
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     if (c->h_fame) (void)hipHostFree(c->h_fame);
