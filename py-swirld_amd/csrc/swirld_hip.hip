@@ -1660,6 +1660,14 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->lo0_h.assign(c->npad, SW_INF);
     c->NEARCAP = std::max(64 * c->npad, 4096);
     c->MCAP = std::max(1024 * c->npad, 65536);
+    if (c->npad > 512) {
+        // 1024 members: the tally runs at the L2 roofline (n^2 / 8 bytes of hop masks per evaluation), so fewer
+        // evaluations per round pay: a round ends >= 10-11 chain positions behind its start there, a window of 12
+        // slots from offset 10 finds it in 1.1 iterations per round at uniform gossip (41.3 -> 48.7 M ev/s at
+        // 2 M events; coin-round stress +8 %, two cliques -5 %: profiles/r03y_*)
+        c->K = 12;
+        c->skip = 10;
+    }
     if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, std::min(63, atoi(s)));  // the candidate table has 64 columns
     if (const char* s = getenv("SW_BAND")) c->NEARCAP = std::max(64, atoi(s));
     if (const char* s = getenv("SW_BAND_MAX")) c->MCAP = std::max(64, atoi(s));

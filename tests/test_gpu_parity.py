@@ -191,6 +191,9 @@ CASES = [
     (256, 40000, 3, 0, 0, 0, None),        # prefix of BASELINE.json configs[2]
     (300, 30000, 42, 0, 0, 0, None),       # 8 mask words
     (600, 30000, 43, 0, 0, 0, None),       # 16 mask words
+    (300, 40000, 45, 2, 0.35, 0.02, 9000), # 8 mask words, coin-round stress, incremental: the wide elections kernel (k_elections_wide)
+    (520, 40000, 46, 2, 0.4, 0.02, None),  # 16 mask words, coin-round stress
+    (700, 30000, 47, 1, 0.02, 0, 7000),    # 16 mask words, two cliques, incremental
 ]
 
 

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("n,N,seed,mode,p0,p1,chunk,nparts", [
     (64, 40000, 501, 0, 0, 0, None, 2), (4, 4000, 502, 0, 0, 0, 300, 3), (130, 20000, 503, 2, 0.2, 0.05, 6000, 4),
-    (256, 60000, 504, 0, 0, 0, None, 8), (16, 8000, 505, 1, 0.02, 0, 1000, 2)])
+    (256, 60000, 504, 0, 0, 0, None, 8), (16, 8000, 505, 1, 0.02, 0, 1000, 2),
+    (300, 30000, 506, 2, 0.35, 0.02, 8000, 3), (520, 30000, 507, 0, 0, 0, None, 2)])   # (more than 256 members: k_elections_wide)
 def test_partitioned_fame_equals_decide_fame(pkg, n, N, seed, mode, p0, p1, chunk, nparts):
     from oracle.oracle import Oracle
     part = importlib.import_module("py-swirld_amd.partition")
