@@ -152,7 +152,7 @@ struct sw_ctx {
     hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr;
     std::vector<int32_t> divided_cnt;   // per member: events already divided (chain positions below `divided`)
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
-    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_nx1, d_nx2, d_nxp1, d_farslot, d_force, d_cand, d_gallop;
+    DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
     DBuf<int32_t> d_rsc;   // [R][3] round-level agreement of k_elections_wide: open witnesses, decided flag, arrival ticket
     DBuf<u64> d_found64;   // [2][npad] {event << 32 | slot << 26 | look-ahead} of the members' first passing candidates (LoopBufs::found64)
@@ -760,7 +760,6 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.lo_r = c->d_lo_r.p; B.cur = c->d_cur.p; B.unres = c->d_unres.p; B.lo_next = c->d_lo_next.p;
     B.pos_next = c->d_pos_next.p; B.evalround = c->d_evalround.p; B.evalpos = c->d_evalpos.p;
     B.found64 = c->d_found64.p;
-    B.nx1 = c->d_nx1.p; B.nx2 = c->d_nx2.p; B.nxp1 = c->d_nxp1.p;
     B.farslot = c->d_farslot.p;
     B.force = c->d_force.p;
     B.cand = c->d_cand.p;
@@ -1773,9 +1772,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CCHK(dgrow(c, c->d_lo_next, 2 * np, 0));
     CCHK(dgrow(c, c->d_pos_next, 2 * np, 0));
     CCHK(dgrow(c, c->d_found64, 2 * np, 0));
-    CCHK(dgrow(c, c->d_nx1, 2 * np, 0));
-    CCHK(dgrow(c, c->d_nx2, 2 * np, 0));
-    CCHK(dgrow(c, c->d_nxp1, 2 * np, 0));
     CCHK(dgrow(c, c->d_farslot, 2 * np, 0));
     CCHK(dgrow(c, c->d_force, 2 * np, 0));
     CCHK(dgrow(c, c->d_cand, (size_t)2 * np * 64, 0));
@@ -1847,7 +1843,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
-    dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_rsc); dfree(c->d_nx1); dfree(c->d_nx2); dfree(c->d_nxp1); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_rsc); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
     if (c->d_rb) (void)hipFree(c->d_rb);
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     if (c->h_fame) (void)hipHostFree(c->h_fame);
