@@ -102,3 +102,20 @@ def test_committed_measurement_fixtures_bench_reads():
     with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
         rp = json.load(f)
     assert rp["reference_equals_oracle_on_this_prefix"] is True and rp["members"] == 256 and rp["events_per_s"] > 0
+
+
+def test_ctypes_structs_mirror_the_header_structs(pkg):
+    """sw_counters / sw_timings are filled by value through a caller-provided pointer: the ctypes mirrors in
+    py-swirld_amd/_lib.py must have the header's fields, in the header's order, with the header's types —
+    a field appended on one side only reads (or overruns) the wrong bytes silently."""
+    import ctypes as C
+    import importlib
+    L = importlib.import_module("py-swirld_amd._lib")
+    header = open(os.path.join(ROOT, "include", "swirld_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    ctype = {"int64_t": C.c_int64, "int32_t": C.c_int32, "float": C.c_float}
+    for name, mirror in (("sw_counters", L.Counters), ("sw_timings", L.Timings)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, flags=re.S).group(1)
+        fields = [(m.group(2), ctype[m.group(1)]) for m in re.finditer(r"\b(int64_t|int32_t|float)\s+([a-z_0-9]+)\s*;", body)]
+        assert fields == list(mirror._fields_), name
+        assert C.sizeof(mirror) == sum(C.sizeof(t) for _, t in fields), name
