@@ -2121,7 +2121,7 @@ __device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) +
 
 template <int NW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 4 ? 8 : 2, 8)))
-k_tally_bits(LoopBufs B, int par, int K, int skip,
+k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
              const int* __restrict__ chain_ev,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
@@ -2135,7 +2135,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     __shared__ int s_fark[4], s_cm[4];
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.cur); pin_arg(B.unres); pin_arg(B.farslot);
-    pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand); pin_arg(B.found64); pin_arg(B.gallop); pin_arg(par); pin_arg(K); pin_arg(skip);
+    pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand); pin_arg(B.found64); pin_arg(B.gallop); pin_arg(par); pin_arg(K); pin_arg(skip); pin_arg(mb_prefetch);
     pin_arg(L); pin_arg(sp); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad); pin_arg((int)gridDim.x);
     RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
     const size_t pb = (size_t)(1 - par) * npad;
@@ -2155,6 +2155,20 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
     // by construction).  Round trip 2: its can_see row and both parents.  Round trip 3: the
     // gathered hop masks.
     const int s_done = st->done, mlo = st->mlo, mhi = st->mhi;
+    // The band-mask table was written by the other XCDs' workgroups; the first waves of every XCD miss on it in
+    // their gathers (2.9 us against 0.9 us for late waves, phase stamps).  The first 64 waves of each XCD touch
+    // one 128-byte line per lane while they wait for their own first round trips (SW_TALLY_PF=0 switches it
+    // off): 7.76 -> 7.69 ms per pass at 256 members / 1 M events.
+    int pf_dummy = 0;
+    if (mb_prefetch) {
+        const int wx = ((int)blockIdx.x >> 3) * 4 + wib;               // wave index within its XCD (block b runs on XCD b mod 8: locality only)
+        const int nlines = ((mhi - mlo + 1) * NW * 8 + 127) >> 7;
+        const int line = wx * 64 + lane;
+        if (wx < 64 && line < nlines) {
+            const char* q = reinterpret_cast<const char*>(Mb32) + (size_t)line * 128;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(q) : "memory");
+        }
+    }
     const int un = B.unres[pb + cm], frc = B.force[pb + cm];
     const int* cand = B.cand + ((size_t)(1 - par) * npad + cm) * 64;
     const int e = cand[cj + 1];  // published by k_resolve_band (-1: no such candidate)
@@ -2248,6 +2262,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip,
         }
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
+    asm volatile("" ::"v"(pf_dummy));   // (the touch's destination register stays reserved to the end)
     SW_STAMP(stamp, it_, sb + 5);
 }
 

@@ -186,6 +186,7 @@ struct sw_ctx {
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int ring_H = 0;       // ring depth chosen at create (power of two)
     int band_blocks = 512; // workgroups of the resolve+band kernel
+    int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
     // round-loop graph
     struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; int K, tally_impl, BATCH, MCAP; };
@@ -790,7 +791,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
     Span s{};
     if (tally_spans) s = span_begin(c);
     if (c->unit_stake && c->tally_impl == 1)
-        hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip,
+        hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, c->tally_pf,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
                            (const uint32_t*)c->d_Mb.p, tot2, np);
@@ -1674,6 +1675,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
     if (const char* s = getenv("SW_GRAPH")) c->use_graph = atoi(s) != 0;
     if (const char* s = getenv("SW_BAND_BLOCKS")) c->band_blocks = std::max(1, std::min(4096, atoi(s)));
+    if (const char* s = getenv("SW_TALLY_PF")) c->tally_pf = atoi(s) != 0;
     if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
     if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
