@@ -7,22 +7,32 @@ Node.add_event, outside the timed region of `value`; `value_end_to_end` includes
 Workload at N=1: BASELINE.json configs[2] — 256 members, 1M events, uniform gossip
 (SURVEY.md §8d generator), seed 3.
 
---gpus N runs N INDEPENDENT replicas of that workload (one hashgraph per GPU, different seeds):
-`"scaling": "weak-replicas"`.  This is NOT the strong-scaling split north_star asks for (one 1M-event
-DAG over 8 GPUs, >= 6x): DESIGN.md §8 explains why the path is latency-bound and what the partitioned
-prototype (py-swirld_amd/partition.py, gloo-tested) would cost; no data-path collective runs here.
+--gpus N measures TWO things in one run and says which one is `value` (`"scaling"`):
+  * N INDEPENDENT replicas of the workload (one hashgraph per GPU, different seeds) — `value`, `"scaling":
+    "weak-replicas"`, the default: what a deployment has (every member holds its own view);
+  * ONE hashgraph over the N GPUs — `value_strong` (with `--split strong` it becomes `value`, `"scaling": "strong"`):
+    py-swirld_amd/partition.py StrongSplit — the can_see sweep split by event ranges (every rank sweeps its
+    range from a halo, no communication), the ranges broadcast as int32 rows over RCCL while the round loop
+    (replicated: one chain of dependent iterations) already works on the ranges that arrived, and the
+    elections candidate-partitioned with one all-reduce.  DESIGN.md §8 says why this cannot reach north_star's
+    >= 6x at 8 GPUs; this number is the evidence.
 
 Extra fields of the JSON line:
   value_end_to_end  events/s from "SoA arrays in host memory" to "round[N], witness table, famous,
                     new_c back in host memory" (SURVEY.md §8d Timing): sw_reset + sw_append_events +
                     sw_divide_rounds + sw_decide_fame + getters, on a context whose device storage is
                     already allocated.  PCIe-inclusive; never `value`.
+  value_with_order  events/s of divide_rounds + decide_fame + find_order (N1, swirld.py:280-311): N / (ms_per_step +
+                    find_order_ms); find_order is outside the metric and timed once, after the profiled pass.
   roofline          the kernel with the largest total time, plus a `kernels` table (every family of
                     the path: algorithmic bytes per launch per SURVEY.md §8d, average launch duration
                     measured live with hipEvents, counter-measured HBM bytes per launch from the
                     same-commit rocprofv3 --pmc passes in profiles/traffic.json) and the whole-path
                     algorithmic rate.
-  cpu_baseline      the C oracle (kind "port") on one host core over a bounded sample.
+  cpu_baseline      the C oracle (kind "port") on one host core over a bounded sample; `reference_python` next to it
+                    is the unmodified reference itself: timed IN THIS RUN on a short prefix when its source tree is
+                    reachable (`--reference-path`, default /root/reference: the authoring container), else the
+                    committed measurement of profiles/reference_python_timing.json (`same_run` says which).
 
 Prints ONE JSON line on rank 0.
 """
@@ -49,16 +59,52 @@ def algorithmic_bytes(n, counters, n_events):
     return dr, df
 
 
+def npad_of(n):
+    return ((n + 63) // 64) * 64
+
+
+def kernels_sha256():
+    import hashlib
+    with open(os.path.join(ROOT, "py-swirld_amd", "csrc", "kernels.hip.h"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def load_traffic():
     """profiles/traffic.json: HBM bytes per launch per kernel family from rocprofv3 --pmc passes
     (FETCH_SIZE doubled + WRITE_SIZE, separate passes) — measured by profiles/collect_traffic.py
-    on the commit named inside; not measured by this run."""
+    on the commit named inside; not measured by this run.  The file carries the SHA-256 of the kernel
+    source it was measured on: figures of other kernels are not quoted (`stale`)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(tpath))
-        return t.get("kernels", {}), t.get("commit"), t.get("workload")
     except Exception:
-        return {}, None, None
+        return {}, None, None, True
+    stale = t.get("kernels_sha256") != kernels_sha256()
+    return ({} if stale else t.get("kernels", {})), t.get("commit"), t.get("workload"), stale
+
+
+def time_python_reference(ref_path, n, stream, events):
+    """The unmodified pure-Python reference on the first `events` events of this run's stream, one core, stdout
+    suppressed (BASELINE.md §3 protocol), through the test harness that imports it (tests/refharness.py)."""
+    if not os.path.isfile(os.path.join(ref_path, "swirld.py")):
+        return None
+    try:
+        sys.path[:0] = [os.path.join(ROOT, "tests")]
+        os.environ.setdefault("SWIRLD_REFERENCE_PATH", ref_path)
+        import refharness
+        M = min(events, len(stream[0]))
+        ref = refharness.RefRun(n)
+        ref.append(*[a[:M] for a in stream])
+        t0 = time.perf_counter()
+        ref.divide_rounds(0, M)
+        ref.decide_fame()
+        dt = time.perf_counter() - t0
+        return {"events_per_s": round(M / dt, 1), "events": M, "members": n, "cores": 1, "seconds": round(dt, 2),
+                "same_run": True, "where": "this run (reference tree at %s)" % ref_path,
+                "note": "prefix-sampled: the cost per event still rises over the first rounds (622 / 433 / 265 events/s on 4 k / 8 k / 15 k "
+                        "events at 256 members in the authoring container), so a longer prefix reads lower"}
+    except Exception as exc:  # noqa: BLE001
+        return {"same_run": False, "error": repr(exc)}
 
 
 def main():
@@ -76,6 +122,13 @@ def main():
     ap.add_argument("--p0", type=float, default=0.0)
     ap.add_argument("--p1", type=float, default=0.0)
     ap.add_argument("--e2e-steps", type=int, default=3, help="end-to-end passes (host arrays in, results on host); 0 = skip")
+    ap.add_argument("--split", choices=["replicas", "strong"], default="replicas",
+                    help="which multi-GPU number is `value`: independent replicas (default) or ONE hashgraph over the GPUs")
+    ap.add_argument("--emulate-parts", type=int, default=0,
+                    help="1 GPU only: also run the one-hashgraph split with this many contexts on the one device (no parallelism: "
+                         "a functional run that reports the per-range sweep time and the rows moved)")
+    ap.add_argument("--reference-path", default="/root/reference", help="source tree of the Python reference (timed in-run when present)")
+    ap.add_argument("--reference-events", type=int, default=8000, help="prefix of the stream timed through the Python reference (~20 s at 256 members)")
     args = ap.parse_args()
 
     import torch
@@ -150,6 +203,75 @@ def main():
                            "sw_divide_rounds + sw_decide_fame + round[N] / witness table / famous read-back"}
         assert len(r_e2e[0]) == N and list(r_e2e[3]) == list(new_c)
 
+    # ---- ONE hashgraph over the GPUs (north_star's split): the same stream on every rank ----
+    strong = None
+    part_mod = importlib.import_module("py-swirld_amd.partition")
+    if world > 1 and npad_of(n) <= 256:
+        import torch.distributed as dist
+        dev = torch.device("cuda", local_rank)
+        s_stream = pkg.synth_hashgraph(n, N, args.seed, args.mode, args.p0, args.p1)
+        hs = pkg.Hashgraph(n, device=local_rank)
+        hs.reserve(N)
+        hs.append_events(*s_stream)
+        ss = part_mod.StrongSplit(dist, rank, world, device=dev)
+        back = part_mod.HipRangeBackend(hs, dev)
+
+        def strong_step():
+            hs.rewind()
+            ss.divide_rounds(back, N)
+            return ss.decide_fame(back)
+
+        for _ in range(max(1, args.warmup)):
+            nc_s = strong_step()
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            nc_s = strong_step()
+        barrier()
+        dts = rep.max_over_ranks(time.perf_counter() - ts0)
+        pv, fx, rs = hs.range_stats()
+        strong = {"events_per_s": round(N * args.steps / dts, 1), "ms_per_step": round(dts / args.steps * 1e3, 3), "parts": world,
+                  "rows_broadcast_bytes_per_step": int(N * npad_of(n) * 4), "provisional_entries": pv, "repaired": fx, "ranges_swept_twice": rs,
+                  "new_c_last_step": int(len(nc_s)),
+                  "what": "sw_rewind + StrongSplit.divide_rounds (range sweeps, %d async broadcasts of int32 rows, replicated round loop) + "
+                          "candidate-partitioned decide_fame (one all-reduce), max over ranks" % world}
+        hs.close()
+    elif world == 1 and args.emulate_parts > 1 and npad_of(n) <= 256:
+        dev = torch.device("cuda", local_rank)
+        P = args.emulate_parts
+        hp = []
+        for _ in range(P):
+            h_ = pkg.Hashgraph(n, device=local_rank)
+            h_.reserve(N)
+            h_.append_events(*stream)
+            hp.append(h_)
+        backs = [part_mod.HipRangeBackend(h_, dev) for h_ in hp]
+        cuts = part_mod.chunk_cuts(0, N, P)
+        sweep_ms = []
+        for k, h_ in enumerate(hp):      # the range sweeps, one at a time: what ONE rank spends before its rows can travel
+            h_.synchronize()
+            tq = time.perf_counter()
+            h_.cansee_range(cuts[k], cuts[k + 1] - cuts[k])
+            h_.range_stats()             # (synchronises the sweep stream)
+            sweep_ms.append((time.perf_counter() - tq) * 1e3)
+            h_.rewind()
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        part_mod.emulate_strong_split(backs, N)
+        tables = [h_.decide_fame_partial(p_, P) for p_, h_ in enumerate(hp)]
+        fam_m, dec_m = part_mod.merge_fame_tables(tables)
+        ncs = [list(h_.commit_fame(fam_m, dec_m)) for h_ in hp]
+        torch.cuda.synchronize()
+        emu_ms = (time.perf_counter() - tq) * 1e3
+        assert all(x == ncs[0] for x in ncs) and list(ncs[0]) == list(new_c)
+        strong = {"emulated_on_one_gpu": True, "parts": P, "range_sweep_ms_each": [round(x, 3) for x in sweep_ms],
+                  "all_parts_one_after_the_other_ms": round(emu_ms, 3),
+                  "rows_moved_bytes": int(N * npad_of(n) * 4 * (P - 1)), "range_stats": [h_.range_stats() for h_ in hp],
+                  "note": "functional run: P contexts on ONE device take turns, so the elapsed time is not a multi-GPU figure; "
+                          "range_sweep_ms_each is what one rank spends before its rows can travel"}
+        for h_ in hp:
+            h_.close()
+
     # ---- per-kernel roofline table: one extra profiled pass (plain launches, hipEvent pairs) ----
     h = ctxs[0]
     h.rewind()
@@ -164,7 +286,7 @@ def main():
     ordered = h.find_order(new_c_prof)   # N1 (outside the metric): reported for information only
     find_order_ms = (time.perf_counter() - t_fo) * 1e3
     cd = {k: c1[k] - c0[k] for k in c1}
-    traffic, traffic_commit, traffic_workload = load_traffic()
+    traffic, traffic_commit, traffic_workload, traffic_stale = load_traffic()
 
     def fam(name, launches, total_ms, alg_bytes_total, served_by, note=None):
         launches = max(1, int(launches))
@@ -180,7 +302,7 @@ def main():
 
     npad = ((n + 63) // 64) * 64
     cs_impl = int(os.environ.get("SW_CANSEE_IMPL", "6" if npad <= 256 else "3"))
-    cs_name = "k_cansee_flow" if cs_impl >= 6 else ("k_cansee_member1b" if npad <= 256 else "k_cansee_stream")
+    cs_name = "k_cansee_flow" if cs_impl >= 6 else "k_cansee_stream"
     cs_note = "12n B per event (2 parent rows read, 1 written); bound by the dependency chain of the DAG (about 3.4 N/n levels)"
     if cd.get("chunk_sweeps", 0) > 0:  # the chunk-parallel sweep ran (k_cansee_chunks: the launch's span includes its gated repair kernels)
         cs_name = "k_cansee_chunks"
@@ -199,11 +321,25 @@ def main():
     dom = max(kernels, key=lambda k: k["total_ms"])
     dr_b, df_b = algorithmic_bytes(n, cd, N)
     path_gbps = (dr_b + df_b) / (ms_per_step * 1e-3) / 1e9
+    # counter-measured HBM bytes of one pass: per-launch figures of the committed --pmc passes x the launches of THIS run
+    # (round loop: iterations that did work; finalize / voter masks: one launch per sub-batch)
+    hbm_pmc = None
+    if traffic:
+        per_pass = {cs_name: tm["cansee_launches"], "k_resolve_band": cd["round_iterations"], "k_tally_bits": cd["round_iterations"],
+                    "k_elections": 1, "k_voter_masks_bits": tm["cansee_launches"], "k_finalize_events": tm["cansee_launches"]}
+        if all(traffic.get(k) is not None for k in (cs_name, "k_resolve_band", "k_tally_bits")):
+            hbm_pmc = int(sum(traffic.get(k, 0) * v for k, v in per_pass.items()))
     roofline = {
         "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": PEAK_GBPS,
         "unit": "GB/s", "frac": dom["frac"], "traffic": dom["hbm_bytes_per_launch_pmc"],
         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, commit %s, %s); "
-                          "not measured by this run" % (traffic_commit, traffic_workload),
+                          "not measured by this run%s" % (traffic_commit, traffic_workload,
+                                                          "; STALE: measured on other kernel source than this tree's, not quoted" if traffic_stale else ""),
+        "traffic_stale": bool(traffic_stale),
+        "hbm_bytes_per_step_pmc": hbm_pmc,
+        "frac_hbm_measured": round(hbm_pmc / (ms_per_step * 1e-3) / 1e9 / PEAK_GBPS, 5) if hbm_pmc else None,
+        "hbm_bytes_note": "sum over kernel families of (PMC bytes per launch, profiles/traffic.json) x (launches of this run's profiled pass) "
+                          "/ ms_per_step: what actually crosses the HBM interface, against algorithmic bytes in path_frac",
         "avg_launch_us": dom["avg_launch_us"], "launches": dom["launches"],
         "dominant_by": "largest total kernel time of the profiled pass",
         "kernels": kernels,
@@ -236,30 +372,52 @@ def main():
                                   "(sequential C restatement of swirld.py:187-277), %.1f s" % (M, tc),
                         "python_reference_note": "the unmodified pure-Python reference cannot travel to the GPU box; in the "
                                                  "authoring container it runs 204 events/s at 256 members (BASELINE.md §3)"}
-        try:  # the reference itself, timed in the authoring container on a prefix of this very stream and compared
-            # with the oracle there (profiles/time_reference_here.py): a committed measurement, not a run of this job
-            with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
-                rp = json.load(f)
-            cpu_baseline["reference_python"] = {k: rp[k] for k in ("events_per_s", "events", "members", "cores", "cpu", "where",
-                                                                   "c_oracle_same_prefix_events_per_s",
-                                                                   "reference_equals_oracle_on_this_prefix") if k in rp}
-        except (OSError, ValueError):
-            pass
+        # the reference itself: timed in THIS run when its tree is reachable (north_star: "timed on the same box's host cores
+        # in the same run"); the GPU box has no /root/reference, there the committed measurement of the authoring
+        # container stands in (profiles/time_reference_here.py: same stream, results compared with the oracle)
+        live = time_python_reference(args.reference_path, n, stream, args.reference_events) if args.reference_events > 0 else None
+        if live and live.get("same_run"):
+            cpu_baseline["reference_python"] = live
+        else:
+            try:
+                with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
+                    rp = json.load(f)
+                cpu_baseline["reference_python"] = {k: rp[k] for k in ("events_per_s", "events", "members", "cores", "cpu", "where",
+                                                                       "c_oracle_same_prefix_events_per_s",
+                                                                       "reference_equals_oracle_on_this_prefix") if k in rp}
+                cpu_baseline["reference_python"]["same_run"] = False
+                if live:
+                    cpu_baseline["reference_python"]["in_run_attempt"] = live.get("error")
+            except (OSError, ValueError):
+                pass
 
+    use_strong = args.split == "strong" and strong is not None and "events_per_s" in strong
+    value_replicas, ms_replicas = value, ms_per_step
+    if use_strong:
+        value, ms_per_step = strong["events_per_s"], strong["ms_per_step"]
     if rank == 0:
         out = {
             "metric": "events/sec through divide_rounds+decide_fame", "value": round(value, 1),
             "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "weak-replicas",
+            "scaling": "weak" if world == 1 else ("strong" if use_strong else "weak-replicas"),
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "value_end_to_end": e2e["events_per_s"] if e2e else None,
             "end_to_end": e2e,
+            "value_replicas": round(value_replicas, 1), "ms_per_step_replicas": round(ms_replicas, 3),
+            "value_strong": strong["events_per_s"] if strong and "events_per_s" in strong else None,
+            "strong": strong,
+            "value_with_order": round(N / ((ms_replicas + find_order_ms) * 1e-3), 1) if world == 1 else None,
+            "find_order_ms": round(find_order_ms, 3),
             "config": {"workload": "%d members, %d events, %s hashgraph, one batch "
                                    "divide_rounds + decide_fame per step" % (
                                        n, N, ["uniform-gossip", "two-clique", "slow-member", "stale-other-parent"][args.mode]),
                        "members": n, "events": N, "seed": args.seed,
-                       "parallelism": "replicas x%d (no data-path collective; strong-scaling target of north_star unmet)" % world,
+                       "timed_region": "`value`: sw_rewind + sw_divide_rounds + sw_decide_fame on a hashgraph already RESIDENT in HBM "
+                                       "(device-resident, the metric); `value_end_to_end`: SURVEY.md §8(d) 'Timing' — host SoA arrays in "
+                                       "-> round[N], witness table, famous, new_c back on the host (ingest and PCIe included)",
+                       "parallelism": ("one hashgraph over %d GPUs: event-range can_see split + RCCL row broadcasts + partitioned decide_fame" % world)
+                                      if use_strong else ("replicas x%d (no data-path collective); the one-hashgraph split is `value_strong`" % world),
                        "rounds": c1["rounds"], "ingest_s_untimed": round(ingest_s, 3),
                        "new_c_last_step": int(len(new_c)),
                        "coin_round_votes": cd["coin_votes"], "coin_round_votes_from_signature_bit": cd["coin_flips"],

@@ -113,6 +113,39 @@ int sw_commit_fame(sw_ctx* ctx, const int8_t* famous, const uint8_t* decided, in
                    int32_t* new_rounds, int cap, int* n_new);
 
 /*
+ * Multi-GPU building block, part 2 (no reference counterpart — its `network` is a dict,
+ * swirld.py:40, 337): the can_see table split by EVENT RANGES.  Every part holds the whole hashgraph
+ * (sw_append_events: 16 B per event) and computes the can_see rows of its own range only; the rows
+ * are exchanged (RCCL broadcast / all-gather of int32 rows, py-swirld_amd/partition.py StrongSplit),
+ * after which sw_divide_rounds finds them in place and runs the round loop without sweeping.
+ *   sw_cansee_range   sweeps the rows of [first, first + K) from a halo in front of the range
+ *                     (the chunk-parallel sweep, k_cansee_chunks: a parent below the halo is a leaf,
+ *                     entries the window cannot know are PROVISIONAL and counted).  Asynchronous.
+ *   sw_cansee_repair  repairs those entries from the final rows below the range — which must have
+ *                     been imported (or computed) before; device-gated: costs nothing when the sweep
+ *                     counted none, sweeps the range again from final rows when they are too many.
+ *                     Ranges are repaired in ascending order.
+ *   sw_export_rows    copies the rows of [first, first + K) to caller-provided DEVICE memory
+ *                     (K * row_stride int32, row_stride = members padded to a multiple of 64:
+ *                     sw_row_stride), ordered after the sweep / repair; `user_stream` (a hipStream_t,
+ *                     may be NULL = the null stream) is made to wait for the copy, so a collective
+ *                     enqueued on it afterwards sends complete rows.
+ *   sw_import_rows    the opposite direction: waits (on the device) for what `user_stream` has
+ *                     enqueued so far, copies the rows into the table and marks them present.
+ * Rows present (swept by sw_cansee_range, imported) are not swept again by sw_divide_rounds; a
+ * sw_divide_rounds call must lie entirely inside or entirely outside the present ranges.
+ * Fast path with at most 256 members and the plain (non-windowed) table only: SW_ENOTSUP otherwise.
+ * sw_get_range_stats synchronises and returns the provisional entries counted, the entries the repair
+ * changed and the ranges swept a second time, since the last sw_rewind.
+ */
+int sw_row_stride(const sw_ctx* ctx);
+int sw_cansee_range(sw_ctx* ctx, int64_t first, int64_t K);
+int sw_cansee_repair(sw_ctx* ctx, int64_t first, int64_t K);
+int sw_export_rows(sw_ctx* ctx, int64_t first, int64_t K, void* dst_device, void* user_stream);
+int sw_import_rows(sw_ctx* ctx, int64_t first, int64_t K, const void* src_device, void* user_stream);
+int sw_get_range_stats(sw_ctx* ctx, int64_t* provisional, int64_t* repaired, int64_t* resweeps);
+
+/*
  * Node.find_order(new_c) (swirld.py:280-311) for the given rounds (processed in
  * ascending order like sorted(new_c)).  Appends to the internal `transactions` list
  * and writes the newly ordered event indices, in final order, to out_events.

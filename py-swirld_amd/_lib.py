@@ -47,6 +47,12 @@ SIGNATURES = {
     "sw_decide_fame": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "sw_decide_fame_partial": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "sw_commit_fame": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "sw_row_stride": (C.c_int, [_P]),
+    "sw_cansee_range": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "sw_cansee_repair": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "sw_export_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "sw_import_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "sw_get_range_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sw_find_order": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "sw_get_height": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_round": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),

@@ -120,138 +120,17 @@ __global__ void k_level_scatter(const int* __restrict__ ht, const int* __restric
     desc[slot] = make_int4(e, sp[e], o, w);
 }
 
-// ---------------------------------------------------------------------------------
-// can_see rows (swirld.py:198, 203-205, 220).  Fork-free DAG: maxi()/higher() by height
-// (swirld.py:170-184) equals max() of the dense indices on one creator's chain.
-// Each workgroup owns CB columns of every row and sweeps the levels in order; levels are
-// separated by a workgroup barrier only (no inter-workgroup dependency at all).
-// ---------------------------------------------------------------------------------
-template <int CB>
-__global__ void __launch_bounds__(1024)
-k_cansee_levels(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-                int* L, int npad) {
-    const int tid = threadIdx.x;
-    const int col = blockIdx.x * CB + (tid % CB);
-    const int sub = tid / CB;
-    constexpr int EPB = 1024 / CB;  // events per pass
-    int s = lev_start[0];
-    for (int lv = 0; lv < nlev; ++lv) {
-        const int t = lev_start[lv + 1];
-        for (int i = s + sub; i < t; i += EPB) {
-            const int4 d = desc[i];  // {e, sp, op, cr}
-            int v = -1;
-            if (d.y >= 0) {
-                const int a = L[(size_t)d.y * npad + col];
-                const int b = L[(size_t)d.z * npad + col];
-                v = a > b ? a : b;
-            }
-            if (col == (d.w & 1023)) v = d.x;
-            L[(size_t)d.x * npad + col] = v;
-        }
-        s = t;
-        __syncthreads();  // rows of this level visible to the whole workgroup
-    }
-}
 
 
-// Same computation with the recent rows kept in LDS.  Per member a ring of H row slices
-// (slot = chain position mod H); a parent row is taken from the ring when it is still
-// there (always for the self-parent, and for the other-parent unless its creator made H or
-// more events since), else from HBM/L2.  Two LDS-only barriers per level (read phase /
-// write phase); the global stores are fire-and-forget: a row can only be re-read from
-// global memory two or more levels after it was stored (the newest slot of a member is
-// always in the ring), and every wave drains its own stores at the start of the next
-// write phase, i.e. one barrier before such a read can be issued.
+// LDS-only workgroup barrier of the level-bucketed sweep (never waits for global memory)
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int CB>
-__global__ void __launch_bounds__(1024)
-k_cansee_ring(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-              int* L, int npad, int H) {
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    int* ring = smem;                              // [npad][H][CB]
-    int* ring_ev = smem + (size_t)npad * H * CB;   // [npad][H]
-    const int tid = threadIdx.x;
-    const int col = tid % CB;
-    const int sub = tid / CB;
-    const int gcol = blockIdx.x * CB + col;
-    constexpr int EPB = 1024 / CB;
-    constexpr int MAXP = 4;
-    const int hm = H - 1;
-    for (int i = tid; i < npad * H; i += 1024) ring_ev[i] = -1;
-    lds_barrier();
-    int s_cur = lev_start[0];
-    int t_cur = lev_start[1];
-    int t_nxt = nlev > 1 ? lev_start[2] : t_cur;
-    int4 dcur[MAXP];
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-        const int i = s_cur + p * EPB + sub;
-        dcur[p] = i < t_cur ? desc[i] : make_int4(-1, -1, -1, 0);
-    }
-    for (int lv = 0; lv < nlev; ++lv) {
-        // software prefetch: descriptors of the next level, level bounds two ahead
-        int4 dn[MAXP];
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) {
-            const int i = t_cur + p * EPB + sub;
-            dn[p] = (lv + 1 < nlev && i < t_nxt) ? desc[i] : make_int4(-1, -1, -1, 0);
-        }
-        const int t_nn = lv + 2 < nlev ? lev_start[lv + 3] : t_nxt;
-        for (int base = s_cur; base < t_cur; base += EPB * MAXP) {
-            if (base != s_cur) {
-#pragma unroll
-                for (int p = 0; p < MAXP; ++p) {
-                    const int i = base + p * EPB + sub;
-                    dcur[p] = i < t_cur ? desc[i] : make_int4(-1, -1, -1, 0);
-                }
-            }
-            int v[MAXP];
-#pragma unroll
-            for (int p = 0; p < MAXP; ++p) {  // read phase
-                const int4 d = dcur[p];
-                v[p] = -1;
-                if (d.x >= 0) {
-                    const int ce = d.w & 1023;
-                    if (d.y >= 0) {
-                        const int co = (d.w >> 10) & 1023;
-                        const int ss = (((d.w >> 20) & 63) - 1) & hm;
-                        const int so = ((d.w >> 26) & 63) & hm;
-                        int a, b;
-                        if (ring_ev[ce * H + ss] == d.y) a = ring[(ce * H + ss) * CB + col];
-                        else a = __hip_atomic_load(&L[(size_t)d.y * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (ring_ev[co * H + so] == d.z) b = ring[(co * H + so) * CB + col];
-                        else b = __hip_atomic_load(&L[(size_t)d.z * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v[p] = a > b ? a : b;
-                    }
-                    if (gcol == ce) v[p] = d.x;
-                }
-            }
-            lds_barrier();  // every read of the ring is done
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own stores of the previous pass
-#pragma unroll
-            for (int p = 0; p < MAXP; ++p) {  // write phase
-                const int4 d = dcur[p];
-                if (d.x >= 0) {
-                    const int ce = d.w & 1023;
-                    const int se = ((d.w >> 20) & 63) & hm;
-                    L[(size_t)d.x * npad + gcol] = v[p];
-                    ring[(ce * H + se) * CB + col] = v[p];
-                    if (col == 0) ring_ev[ce * H + se] = d.x;
-                }
-            }
-            lds_barrier();
-        }
-        s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn;
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) dcur[p] = dn[p];
-    }
-}
 
 
-// Third version of the can_see sweep: LDS ring (as above) + the level descriptors streamed
+// Level-bucketed can_see sweep (round 1; serves more than 256 members): per member an LDS ring of the H most
+// recent row slices (slot = chain position mod H) + the level descriptors streamed
 // through an LDS staging ring a chunk ahead (no global-memory latency on the per-level
 // critical path) + no per-level drain of the global stores: a workgroup-wide drain + barrier
 // is taken only in the (rare) levels where some parent row is not in the ring and has to be
@@ -376,275 +255,13 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
 }
 
 
-// Fourth version: one THREAD per member, one COLUMN per workgroup (npad workgroups, so every
-// CU sweeps the DAG for a few columns), plus one LOADER wave per workgroup.
-//  * A level holds at most one event per member, so worker thread m simply waits for "its"
-//    event of the level; the row value of m's previous event (the self-parent) stays in a
-//    register, the other-parent's value comes from an LDS ring of {event id, value} pairs.
-//    Per level: ~2 LDS round trips and two barriers of (npad/64 + 1) waves.
-//  * Wave specialisation: the loader wave streams the level descriptors and the level bounds
-//    from HBM into LDS rings far ahead of their use and never stores; the worker waves only
-//    store (fire-and-forget row values) and never load in steady state.  Loads and stores
-//    share one in-order counter (vmcnt) per wave on gfx950, so keeping them in different waves
-//    is what keeps every wait off the per-level critical path.
-//  * A ring miss (other-parent older than H events of its creator, or from an earlier batch)
-//    takes a workgroup-wide drain + barrier + re-read path (rare).
-template <int PENDL>
-__global__ void __launch_bounds__(320)
-k_cansee_member(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-                const int* __restrict__ prev_head, int* prev_head_out, int* L, int npad, int H, int chs) {
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    constexpr int NS = 4;     // descriptor chunks resident
-    constexpr int LVR = 256;  // level-bound ring entries
-    const int CH = 1 << chs;  // descriptors per chunk = 64 * PENDL
-    int4* dstage = (int4*)smem;                                   // [NS][CH]
-    int4* mbox = dstage + (size_t)NS * CH;                        // [2][npad]
-    u64* ring = (u64*)(mbox + 2 * (size_t)npad);                  // [npad][H] {value << 32 | id}
-    int* lvb = (int*)(ring + (size_t)npad * H);                   // [LVR] lev_start ring
-    int* s_miss = lvb + LVR;                                      // [2]
-    const int tid = threadIdx.x;
-    const int BT = blockDim.x;            // npad workers + 64 loader lanes
-    const bool loader = tid >= npad;
-    const int m = tid;                    // member handled by a worker thread
-    const int ll = tid - npad;            // loader lane
-    const int nblk = gridDim.x;
-    const int col = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
-    const int hm = H - 1;
-    const int total = lev_start[nlev];
-    // ---- prologue (everybody helps)
-    for (int i = tid; i < npad * H; i += BT) ring[i] = 0xffffffffffffffffull;  // id -1: empty
-    for (int i = tid; i < 2 * npad; i += BT) mbox[i] = make_int4(-1, -1, -1, 0);
-    if (tid < 2) s_miss[tid] = 0;
-    for (int i = tid; i < 2 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
-    for (int i = tid; i < 128; i += BT) lvb[i] = lev_start[i < nlev ? i : nlev];
-    int pend_q = 2;       // loader: next descriptor chunk to make resident (held in pend[])
-    int4 pend[PENDL];
-    int lpend = 0;        // loader: level bounds [lv+128, lv+192) in flight
-    int mine = -1;        // worker: row value of the member's latest event
-    int last_e = -1;      // worker: the member's latest event (handed to the next batch)
-    if (loader) {
-#pragma unroll
-        for (int k = 0; k < PENDL; ++k) {
-            const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
-            pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
-        }
-        const int j = 128 + ll;
-        lpend = lev_start[j < nlev ? j : nlev];
-    } else {
-        const int ph = prev_head[m];
-        last_e = ph;
-        if (ph >= 0) mine = L[(size_t)ph * npad + col];
-    }
-    lds_barrier();
-    int t_cur = lvb[1], t_nxt = lvb[2 & (LVR - 1)];
-    if (!loader) {  // mailbox of level 0
-        for (int i = lvb[0] + m; i < t_cur; i += npad) {
-            const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
-            mbox[dd.w & 1023] = dd;
-        }
-    }
-    lds_barrier();
-    for (int lv = 0; lv < nlev; ++lv) {
-        const int t_nn = lvb[(lv + 3) & (LVR - 1)];  // end of level lv+2 (clamped entries = total)
-        int4* box = mbox + (size_t)(lv & 1) * npad;
-        int4* nbox = mbox + (size_t)((lv + 1) & 1) * npad;
-        int4 d = make_int4(-1, -1, -1, 0);
-        int other = -1;
-        bool miss = false;
-        if (loader) {
-            // descriptor chunks needed by the mailbox scatter of the NEXT level, one level early
-            const int need_q = t_nn > 0 ? (t_nn - 1) >> chs : 0;
-            while (need_q + 1 >= pend_q) {  // one chunk of lookahead: pend[] has a whole chunk-time to land
-#pragma unroll
-                for (int k = 0; k < PENDL; ++k) dstage[(size_t)(pend_q % NS) * CH + ll + 64 * k] = pend[k];
-                ++pend_q;
-#pragma unroll
-                for (int k = 0; k < PENDL; ++k) {
-                    const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
-                    pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
-                }
-            }
-            if ((lv & 63) == 0) {  // level bounds: LDS holds [lv, lv+128), lpend = [lv+128, lv+192)
-                lvb[(lv + 128 + ll) & (LVR - 1)] = lpend;
-                const int j = lv + 192 + ll;
-                lpend = lev_start[j < nlev ? j : nlev];
-            }
-            if (ll == 0) s_miss[(lv + 1) & 1] = 0;
-        } else {
-            // ---- read phase
-            d = box[m];
-            if (d.x >= 0 && d.z >= 0) {
-                const u64 pr = ring[(size_t)((d.w >> 10) & 1023) * H + (((d.w >> 26) & 63) & hm)];
-                if ((int)(unsigned)pr == d.z) other = (int)(pr >> 32);
-                else { miss = true; s_miss[lv & 1] = 1; }
-            }
-            for (int i = t_cur + m; i < t_nxt; i += npad) {  // mailbox of the next level
-                const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
-                nbox[dd.w & 1023] = dd;
-            }
-        }
-        lds_barrier();
-        if (s_miss[lv & 1]) {  // rare, workgroup-uniform
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            if (miss) other = __hip_atomic_load(&L[(size_t)d.z * npad + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- write phase
-        if (d.x >= 0) {
-            int v = mine > other ? mine : other;
-            if (col == m) v = d.x;
-            mine = v;
-            last_e = d.x;
-            L[(size_t)d.x * npad + col] = v;
-            ring[(size_t)m * H + (((d.w >> 20) & 63) & hm)] = ((u64)(unsigned)v << 32) | (unsigned)d.x;
-            box[m].x = -1;  // consumed
-        }
-        lds_barrier();
-        t_cur = t_nxt; t_nxt = t_nn;
-    }
-    if (blockIdx.x == 0 && !loader) prev_head_out[m] = last_e;
-}
 
 
-// Fifth version = the fourth with ONE barrier per level:
-//  * the loader wave also scatters the next level's descriptors into the member mailboxes;
-//  * workers read their ring entries and write their new entry in the same phase.  The only
-//    entry a reader could see being overwritten is the one exactly H events older than its
-//    creator's event of this level; readers never touch it: they compare the wanted chain
-//    position with the creator's newest position (a per-member LDS word, read racily with a
-//    margin of two) and take the memory path for anything H-2 or more positions old;
-//  * no workgroup-wide drain for that memory path: worker waves issue nothing but stores (at
-//    most one store instruction per level), so `s_waitcnt vmcnt(6)` once per level guarantees
-//    that every row stored seven or more levels ago has reached L2 — and a row that old is the
-//    only kind that can miss the ring (H >= 16).  Rows of earlier kernels are visible anyway.
-template <int PENDL>
-__global__ void __launch_bounds__(320)
-k_cansee_member1b(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-                  const int* __restrict__ prev_head, int* prev_head_out, int* L, int npad, int H, int chs) {
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    constexpr int NS = 4;
-    constexpr int LVR = 256;
-    const int CH = 1 << chs;
-    int4* dstage = (int4*)smem;                                   // [NS][CH]
-    int4* mbox = dstage + (size_t)NS * CH;                        // [3][npad] mailboxes, 2 levels ahead
-    u64* ring = (u64*)(mbox + 3 * (size_t)npad);                  // [npad][H] {value << 32 | id}
-    int* lvb = (int*)(ring + (size_t)npad * H);                   // [LVR]
-    int* newest = lvb + LVR;                                      // [npad] newest chain position & 63
-    const int tid = threadIdx.x;
-    const int BT = blockDim.x;
-    const bool loader = tid >= npad;
-    const int m = tid;
-    const int ll = tid - npad;
-    const int nblk = gridDim.x;
-    const int col = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
-    const int hm = H - 1;
-    const int total = lev_start[nlev];
-    for (int i = tid; i < npad * H; i += BT) ring[i] = 0xffffffffffffffffull;
-    for (int i = tid; i < 3 * npad; i += BT) mbox[i] = make_int4(-1, -1, -1, 0);
-    for (int i = tid; i < npad; i += BT) newest[i] = 0;
-    for (int i = tid; i < 2 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
-    for (int i = tid; i < 128; i += BT) lvb[i] = lev_start[i < nlev ? i : nlev];
-    int pend_q = 2;
-    int4 pend[PENDL];
-    int lpend = 0;
-    int mine = -1;
-    int last_e = -1;
-    int last_store = -1000;
-    if (loader) {
-#pragma unroll
-        for (int k = 0; k < PENDL; ++k) {
-            const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
-            pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
-        }
-        const int j = 128 + ll;
-        lpend = lev_start[j < nlev ? j : nlev];
-    } else {
-        const int ph = prev_head[m];
-        last_e = ph;
-        if (ph >= 0) mine = L[(size_t)ph * npad + col];
-    }
-    lds_barrier();
-    int t_nxt = 0, t_nn = 0;  // loader: ends of levels lv+1 and lv+2
-    if (loader) {
-        const int t0 = lvb[0], t1 = lvb[1];
-        t_nxt = lvb[2];
-        t_nn = lvb[3];
-        for (int i = t0 + ll; i < t_nxt; i += 64) {  // mailboxes of levels 0 and 1
-            const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
-            mbox[(size_t)(i < t1 ? 0 : 1) * npad + (dd.w & 1023)] = dd;
-        }
-    }
-    lds_barrier();
-    int4 d = make_int4(-1, -1, -1, 0);
-    if (!loader) d = mbox[m];  // level 0
-    int b_cur = 0, b_nxt = 1, b_nn = 2;  // mailbox buffers of levels lv, lv+1, lv+2
-    for (int lv = 0; lv < nlev; ++lv) {
-        if (loader) {
-            const int t_n3 = lvb[(lv + 4) & (LVR - 1)];  // end of level lv+3
-            int4* nbox = mbox + (size_t)b_nn * npad;
-            for (int i = t_nxt + ll; i < t_nn; i += 64) {  // mailbox of level lv+2
-                const int4 dd = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
-                nbox[dd.w & 1023] = dd;
-            }
-            const int need_q = t_n3 > 0 ? (t_n3 - 1) >> chs : 0;
-            while (need_q + 1 >= pend_q) {
-#pragma unroll
-                for (int k = 0; k < PENDL; ++k) dstage[(size_t)(pend_q % NS) * CH + ll + 64 * k] = pend[k];
-                ++pend_q;
-#pragma unroll
-                for (int k = 0; k < PENDL; ++k) {
-                    const size_t gi = (size_t)pend_q * CH + ll + 64 * k;
-                    pend[k] = gi < (size_t)total ? desc[gi] : make_int4(-1, -1, -1, 0);
-                }
-            }
-            if ((lv & 63) == 0) {
-                lvb[(lv + 128 + ll) & (LVR - 1)] = lpend;
-                const int j = lv + 192 + ll;
-                lpend = lev_start[j < nlev ? j : nlev];
-            }
-            t_nxt = t_nn;
-            t_nn = t_n3;
-        } else {
-            // next level's descriptor (scattered a level ago): issued first so that its LDS
-            // latency overlaps the ring lookup below
-            const int4 dnext = mbox[(size_t)b_nxt * npad + m];
-            if (d.x >= 0) {
-                int other = -1;
-                if (d.z >= 0) {
-                    const int co = (d.w >> 10) & 1023;
-                    const int so6 = (d.w >> 26) & 63;
-                    const u64 pr = ring[(size_t)co * H + (so6 & hm)];
-                    const int age = (newest[co] - so6) & 63;
-                    if (age < H - 2 && (int)(unsigned)pr == d.z) other = (int)(pr >> 32);
-                    else other = __hip_atomic_load(&L[(size_t)d.z * npad + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                int v = mine > other ? mine : other;
-                if (col == m) v = d.x;
-                mine = v;
-                last_e = d.x;
-                const int se6 = (d.w >> 20) & 63;
-                L[(size_t)d.x * npad + col] = v;
-                ring[(size_t)m * H + (se6 & hm)] = ((u64)(unsigned)v << 32) | (unsigned)d.x;
-                newest[m] = se6;
-                mbox[(size_t)b_cur * npad + m].x = -1;  // consumed
-            }
-            // store-completion bound: at most 6 store instructions of this wave in flight, and
-            // a lone store is drained explicitly six levels after it was issued
-            if (__ballot(d.x >= 0)) last_store = lv;
-            if (lv - last_store == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            d = dnext;
-        }
-        lds_barrier();
-        const int t = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = t;
-    }
-    if (blockIdx.x == 0 && !loader) prev_head_out[m] = last_e;
-}
 
 // ---------------------------------------------------------------------------------
-// Sixth version: DATAFLOW sweep — no DAG levels, no heights, no barriers.
+// DATAFLOW sweep — no DAG levels, no heights, no barriers.
 //
-// The level-synchronous kernels above pay one workgroup barrier (~0.45 us) per DAG level and
+// The level-synchronous kernel above pays one workgroup barrier (~0.45 us) per DAG level and
 // need the events bucketed by height first.  Here every member's self-parent chain is walked by
 // one lane at its own pace: the lane's next event needs (a) the member's previous row value,
 // which stays in a register, and (b) the other-parent's value, which the lane POLLS for in an LDS
@@ -2977,6 +2594,123 @@ k_order_times(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, in
     if (lane == 0) ts[idx] = .5 * (r1 + r2);
 }
 
+
+// ---------------------------------------------------------------------------------
+// Bulk form of the same samples (a call that orders many events at once): instead of one binary
+// search of ~10 scattered 4-byte gathers per (event, famous witness) pair, ONE streaming pass builds
+// the transposed question "which is the first event of member m that sees x?" for every x that is
+// being ordered:
+//   FD[x][m] = min { y on m's chain : can_see[y][creator(x)] >= x }.
+// An event y newly sees, of member c's chain, exactly the positions (seq[L[sp(y)][c]], seq[L[y][c]]]
+// — what its row has beyond its self-parent's row — so thread (y, c) reads two table entries
+// (coalesced along c: whole 128-byte lines of the two rows) and writes FD[x][creator(y)] = y for the
+// few x in that range (one per (y, c) on average; every FD entry is written at most once).  The
+// consumer reads FD rows: "w sees x" is FD[x][creator(w)] <= w, and the sample (swirld.py:298-303, Q11)
+// is the timestamp of FD's self-parent (or of FD itself when it is a root).
+// Workgroup b handles the columns of group b % 8 (= its XCD, for locality only): the FD rows of one
+// chain are written from ONE XCD, whose L2 merges the 4-byte stores of a row's lines before they
+// leave (the rows being filled at any time are the recent ~13 n events: < 1 MB per XCD).
+// ---------------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(256)
+k_order_firstdesc(const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
+                  const int* __restrict__ seq, const int* __restrict__ chain_start, const int* __restrict__ chain_ev,
+                  const int* __restrict__ ordlo, const int* __restrict__ ordhi, int y0, int y1, int x0, int first_resident,
+                  int ytile, int* FD) {
+    constexpr int npad = 64 * NW;
+    constexpr int CG = npad / 8;          // columns per group
+    constexpr int YB = 256 / CG;          // events per pass of a workgroup
+    const int xg = blockIdx.x & 7, tile = blockIdx.x >> 3;
+    const int c = xg * CG + (int)(threadIdx.x % CG);
+    const int yl = (int)(threadIdx.x / CG);
+    const int plo = ordlo[c], phi = ordhi[c];   // chain positions of c ordered by this call: [plo, phi)
+    if (phi <= plo) return;
+    const int cs = chain_start[c];
+    const int ya = y0 + tile * ytile;
+    const int yb = ya + ytile < y1 ? ya + ytile : y1;
+    for (int y = ya + yl; y < yb; y += YB) {
+        const int v = L[(size_t)y * npad + c];
+        if (v < 0) continue;
+        const int s = sp[y];
+        int lower = 0;
+        if (s >= 0) {
+            if (s < first_resident) lower = plo;   // an evicted row is an ordered event's: it sees nothing unordered
+            else {
+                const int pv = L[(size_t)s * npad + c];
+                if (pv == v) continue;             // nothing new of c
+                lower = pv >= 0 ? seq[pv] + 1 : 0;
+            }
+        }
+        int upper = seq[v];
+        lower = lower > plo ? lower : plo;
+        upper = upper < phi - 1 ? upper : phi - 1;
+        if (upper < lower) continue;
+        const int m = cr[y];
+        for (int p = lower; p <= upper; ++p) {
+            const int x = chain_ev[cs + p];
+            FD[(size_t)(x - x0) * npad + m] = y;
+        }
+    }
+}
+
+template <int MAXS>
+__global__ void __launch_bounds__(256)
+k_order_times_fd(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, int n_acc,
+                 const int* __restrict__ fw_ev, const int* __restrict__ fw_cr, const int* __restrict__ fw_off,
+                 const int* __restrict__ FD, int x0, const int* __restrict__ sp, const double* __restrict__ t, int npad,
+                 double* ts, int* err) {
+    __shared__ double s_t[4][MAXS];
+    const int lane = lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 4 + wib;
+    if (idx >= n_acc) return;
+    const int x = acc_ev[idx];
+    const int ri = acc_ri[idx];
+    const int f0 = fw_off[ri], f1 = fw_off[ri + 1];
+    const int* row = FD + (size_t)(x - x0) * npad;
+    double* st = s_t[wib];
+    int len = 0;
+    for (int base = f0; base < f1; base += 64) {
+        const int i = base + lane;
+        bool sees = false;
+        double sample = 0.0;
+        if (i < f1) {
+            const int w = fw_ev[i];
+            const int y = row[fw_cr[i]];
+            if (y >= 0 && y <= w) {   // the first event of w's creator that sees x is w or a self-ancestor of w: w sees x (swirld.py:291-292)
+                sees = true;
+                const int a = sp[y];
+                sample = t[a >= 0 ? a : y];   // its self-parent: the first self-ancestor that does NOT see x; a root stands for itself (Q11)
+            }
+        }
+        const u64 bal = __ballot(sees);
+        if (sees) st[len + __popcll(bal & ((1ull << lane) - 1ull))] = sample;
+        len += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int k1 = len / 2, k2 = (len + 1) / 2;
+    if (k2 >= len) {  // IndexError in the reference (len == 1, only with unequal stakes)
+        if (lane == 0) { atomicExch(err, 1); ts[idx] = 0.0; }
+        return;
+    }
+    double v1 = 0.0, v2 = 0.0;
+    bool h1 = false, h2 = false;
+    for (int i = lane; i < len; i += 64) {
+        const double ti = st[i];
+        int rank = 0;
+        for (int j = 0; j < len; ++j) {
+            const double tj = st[j];
+            rank += (tj < ti) || (tj == ti && j < i);
+        }
+        if (rank == k1) { v1 = ti; h1 = true; }
+        if (rank == k2) { v2 = ti; h2 = true; }
+    }
+    const u64 b1 = __ballot(h1), b2 = __ballot(h2);
+    const int l1 = __ffsll((long long)b1) - 1, l2 = __ffsll((long long)b2) - 1;
+    const double r1 = __shfl(v1, l1), r2 = __shfl(v2, l2);
+    if (lane == 0) ts[idx] = .5 * (r1 + r2);
+}
 
 // whitening key of a decided round (swirld.py:285): XOR of its famous witnesses' signatures
 __global__ void k_order_white(const int* __restrict__ fw_ev, const int* __restrict__ fw_off,

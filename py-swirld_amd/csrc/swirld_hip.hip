@@ -13,11 +13,13 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/swirld_hip.h"
 #include "kernels.hip.h"
 #define SW_PROV_ROWS 16   // sub-batches of one divide_rounds call that can be swept in chunks
+#define SW_RANGE_SLOTS 16 // event ranges swept by sw_cansee_range between two rewinds
 #include "crypto.hip.h"
 #include "exact.hip.h"
 
@@ -118,9 +120,18 @@ struct sw_ctx {
     struct ChunkPlan { int G = 0; int row0 = 0; int64_t a[SW_MAX_CHUNKS + 1]; int64_t w[SW_MAX_CHUNKS]; };
     std::vector<ChunkPlan> chunk_plan;   // per sub-batch of the running call
     std::vector<long long> ccuts_stage;  // host staging of the chunk cuts (persistent: uploaded without a sync)
+    // multi-GPU split of the can_see table by event ranges (sw_cansee_range / sw_import_rows): the ranges swept here,
+    // the rows present in the table without having been divided yet, their cut tables and counters
+    struct RangeRec { int64_t first = 0, K = 0; ChunkPlan pl; int row0 = 0; int slot = 0; bool repaired = false; };
+    std::vector<RangeRec> ranges;
+    std::vector<std::pair<int64_t, int64_t>> present;   // [a, b) rows present, sorted, merged
+    DBuf<int32_t> d_rbnd;
+    DBuf<long long> d_rcuts;
+    std::vector<long long> rcuts_stage;
+    unsigned* d_rprov = nullptr;      // [SW_RANGE_SLOTS][SW_MAX_CHUNKS + 1]: provisional entries per chunk, repaired entries
+    hipEvent_t ev_user = nullptr;
     std::vector<int32_t> chain_cap;   // per member: capacity of its segment
     int64_t pool_used = 0;             // ints of the chain pool handed out
-    DBuf<int32_t> d_prev_head;    // 2 x npad (ping-pong): latest divided event per member (-1 none)
     DBuf<int32_t> d_chain_len;    // npad: events per member visible to the running round loop
     std::vector<int32_t> blk_hmin, blk_hmax;  // height span per 4096-event block (ingest-time index)
     std::vector<int32_t> divided_head;
@@ -180,11 +191,10 @@ struct sw_ctx {
     int MCAP = 0;      // largest band (events) the mask table can hold
     int NEARCAP = 0;   // band cap at round entry (doubles up to MCAP when a far candidate needs a tally)
     int BATCH = 24;    // loop iterations between host checks
-    int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers; k_cansee_flow); 4/5 = member-per-thread + loader wave, two / one barrier per level (npad <= 256); 0 = global-memory levels, 1 = LDS ring, 2/3 = LDS ring + streamed descriptors (1024 / 256 threads)
+    int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers: k_cansee_chunks / k_cansee_flow); 2 / 3 = level-bucketed sweep (k_cansee_stream, 1024 / 256 threads: the default beyond 256 members)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
     int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
-    int ring_H = 0;       // ring depth chosen at create (power of two)
     int band_blocks = 512; // workgroups of the resolve+band kernel
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
@@ -208,6 +218,7 @@ struct sw_ctx {
     std::vector<unsigned char> sig_h;        // host copy of the signatures (whitening, sort key)
     std::vector<int32_t> chain_start_h, chain_ev_h;
     DBuf<int32_t> d_fw_ev, d_fw_off, d_q, d_acc_ev, d_acc_ri, d_sorted, d_hostflag;
+    DBuf<int32_t> d_fw_cr, d_fd, d_ordhi;   // bulk find_order: creators of the famous witnesses, first-descendant table, end of the ordered chain segments
     DBuf<long long> d_acc_off;
     DBuf<unsigned char> d_white;
     DBuf<double> d_ts;
@@ -371,6 +382,13 @@ void vm_destroy(sw_ctx* c) {
     (void)vm_flush_translations(c);
 }
 
+// elements of the (non-windowed) can_see table for `cap` events: the rows, and behind the last row the scratch rows
+// of the chunk-parallel sweep's halos (k_cansee_chunks: SW_MAX_CHUNKS x halo rows).  ONE place decides the size:
+// ensure_events and sw_set_window(0) both allocate through it, and the chunk planner checks it.
+size_t table_elems(const sw_ctx* c, int64_t cap) {
+    return (size_t)(cap + (c->npad <= 256 ? SW_MAX_CHUNKS * c->halo : 0)) * c->npad;
+}
+
 int ensure_events(sw_ctx* c, int64_t need) {
     if (need <= c->cap) return SW_OK;
     int64_t nc = c->cap ? c->cap : 0;
@@ -389,7 +407,7 @@ int ensure_events(sw_ctx* c, int64_t need) {
     CHK(dgrow(c, c->d_S, (size_t)nc * c->nw, keep * c->nw));
     // (windowed table: chunks are mapped per append.)  Behind the last row: the scratch rows of the chunk-parallel
     // sweep's halos (k_cansee_chunks), SW_MAX_CHUNKS x halo rows
-    if (!c->vm.active) CHK(dgrow(c, c->d_L, (size_t)(nc + (c->npad <= 256 ? SW_MAX_CHUNKS * c->halo : 0)) * c->npad, keep * c->npad));
+    if (!c->vm.active) CHK(dgrow(c, c->d_L, table_elems(c, nc), keep * c->npad));
     c->cap = nc;
     return SW_OK;
 }
@@ -591,56 +609,17 @@ int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
 }
 
 template <int NW>
-int launch_cansee(sw_ctx* c, int nlev, int pp) {
-    hipStream_t strm = c->stream_cs;
-    const int* ph_in = c->d_prev_head.p + (size_t)(pp & 1) * c->npad;
-    int* ph_out = c->d_prev_head.p + (size_t)((pp + 1) & 1) * c->npad;
-    constexpr int CB = 16;
-    if ((c->cansee_impl == 4 || c->cansee_impl == 5) && c->npad <= 256) {
-        // member-per-thread kernel: npad workgroups of npad workers + one loader wave
-        const int chs = 10, CH = 1 << chs;
-        int H = 16;
-        if (c->cansee_impl == 5 && c->ring_H_req > 0 && c->ring_H_req < 16) c->ring_H_req = 16;
-        if (c->ring_H_req >= 1 && c->ring_H_req <= 64 && (c->ring_H_req & (c->ring_H_req - 1)) == 0) H = c->ring_H_req;
-        const size_t lds = (size_t)4 * CH * 16 + (size_t)2 * c->npad * 16 + (size_t)c->npad * H * 8 + 256 * 4 + 16;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_cansee_member<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                (void)hipGetLastError();
-            attr_set = true;
-        }
-        if (c->cansee_impl == 5) {
-            static bool attr_set5 = false;
-            if (!attr_set5) {
-                if (hipFuncSetAttribute((const void*)k_cansee_member1b<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                    (void)hipGetLastError();
-                attr_set5 = true;
-            }
-            hipLaunchKernelGGL(k_cansee_member1b<16>, dim3(c->npad), dim3(c->npad + 64), lds + (size_t)c->npad * 4 + (size_t)c->npad * 16, strm,
-                               (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, ph_in, ph_out,
-                               c->d_L.p, c->npad, std::max(H, 16), chs);
-        } else
-        hipLaunchKernelGGL(k_cansee_member<16>, dim3(c->npad), dim3(c->npad + 64), lds, strm,
-                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, ph_in, ph_out,
-                           c->d_L.p, c->npad, H, chs);
-    } else if (c->cansee_impl >= 2) {
-        const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req, c->cansee_impl);
-        if (g.BT == 256 && g.MAXP == 1) CHK((launch_cansee_stream<4, 1, 256>(c, nlev, g)));
-        else if (g.BT == 256 && g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 256>(c, nlev, g)));
-        else if (g.BT == 256) CHK((launch_cansee_stream<4, 4, 256>(c, nlev, g)));
-        else if (g.CB == 16 && g.MAXP == 1) CHK((launch_cansee_stream<16, 1, 1024>(c, nlev, g)));
-        else if (g.CB == 16 && g.MAXP == 2) CHK((launch_cansee_stream<16, 2, 1024>(c, nlev, g)));
-        else if (g.CB == 16) CHK((launch_cansee_stream<16, 4, 1024>(c, nlev, g)));
-        else if (g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 1024>(c, nlev, g)));
-        else CHK((launch_cansee_stream<4, 4, 1024>(c, nlev, g)));
-    } else if (c->cansee_impl == 1 && c->ring_H >= 1) {
-        const size_t lds = ((size_t)c->npad * c->ring_H * CB + (size_t)c->npad * c->ring_H) * sizeof(int);
-        hipLaunchKernelGGL(k_cansee_ring<CB>, dim3(c->npad / CB), dim3(1024), lds, strm,
-                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, c->ring_H);
-    } else {
-        hipLaunchKernelGGL(k_cansee_levels<CB>, dim3(c->npad / CB), dim3(1024), 0, strm,
-                           (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad);
-    }
+int launch_cansee(sw_ctx* c, int nlev, int /*pp*/) {
+    // the level-bucketed streaming kernel (SW_CANSEE_IMPL = 2 / 3: 1024 / 256 threads per workgroup at <= 256 members)
+    const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req, c->cansee_impl);
+    if (g.BT == 256 && g.MAXP == 1) CHK((launch_cansee_stream<4, 1, 256>(c, nlev, g)));
+    else if (g.BT == 256 && g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 256>(c, nlev, g)));
+    else if (g.BT == 256) CHK((launch_cansee_stream<4, 4, 256>(c, nlev, g)));
+    else if (g.CB == 16 && g.MAXP == 1) CHK((launch_cansee_stream<16, 1, 1024>(c, nlev, g)));
+    else if (g.CB == 16 && g.MAXP == 2) CHK((launch_cansee_stream<16, 2, 1024>(c, nlev, g)));
+    else if (g.CB == 16) CHK((launch_cansee_stream<16, 4, 1024>(c, nlev, g)));
+    else if (g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 1024>(c, nlev, g)));
+    else CHK((launch_cansee_stream<4, 4, 1024>(c, nlev, g)));
     c->ctr.kernel_launches++;
     HIPCHK(c, hipGetLastError());
     return SW_OK;
@@ -666,14 +645,18 @@ int launch_cansee_flow_t(sw_ctx* c, int i, int64_t first_event) {
     return SW_OK;
 }
 
-// chunk-parallel dataflow sweep of sub-batch i (k_cansee_chunks): all chunks in ONE launch, then per chunk
-// k >= 1 the repair of its provisional entries and the second sweep — both always enqueued, both gated on
-// the device by the count the sweep left (nothing to read back, no host decision on the sweep stream)
+// chunk-parallel dataflow sweep (k_cansee_chunks) of one plan: all chunks in ONE launch (`sweep_all`), then per
+// chunk k >= k_from the repair of its provisional entries and the second sweep — both always enqueued, both gated
+// on the device by the count the sweep left (nothing to read back, no host decision on the sweep stream).
+// `a0_all`: rows below it are final in memory; a parent in [a0_all, w_k) is a leaf.  A sub-batch of
+// sw_divide_rounds passes its first event (chunk 0 has no halo, repairs start at chunk 1); an event range of the
+// multi-GPU split (sw_cansee_range) passes 0: nothing below its halo is on this device yet, and its repair
+// (sw_cansee_repair, chunk 0 included) runs once the rows below it have been imported.
 template <int NW, int C, int F, int H>
-int launch_cansee_chunks_t(sw_ctx* c, int i) {
+int launch_cansee_chunks_t(sw_ctx* c, const sw_ctx::ChunkPlan& pl, const int* bnd, unsigned* prov, unsigned* fixed,
+                           int a0_all, bool sweep_all, int k_from, int k_to) {
     constexpr int npad = 64 * NW;
     constexpr int NCG = npad / C;
-    const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
     const size_t lds = (size_t)npad * ((size_t)F * 16 + (size_t)(C / 2) * H * 16 + 8);
     const bool wide = ((size_t)c->cap + (size_t)SW_MAX_CHUNKS * (size_t)c->halo) * (size_t)npad * sizeof(int32_t) >= (1ull << 32);
     static bool attr_set = false;
@@ -684,31 +667,30 @@ int launch_cansee_chunks_t(sw_ctx* c, int i) {
     }
     ChunkEv ce{};
     for (int k = 0; k < pl.G; ++k) { ce.w[k] = (int)pl.w[k]; ce.a[k] = (int)pl.a[k]; }
-    const int* bnd = (const int*)c->d_cbnd.p + (size_t)pl.row0 * npad;
-    unsigned* prov = c->d_prov + (size_t)i * SW_MAX_CHUNKS;
-    unsigned* fixed = c->d_prov + (size_t)SW_PROV_ROWS * SW_MAX_CHUNKS + i;
     hipStream_t cs = c->stream_cs;
     auto sweep = [&](int grid, int exact_chunk, unsigned limit) {
         if (wide)
             hipLaunchKernelGGL((k_cansee_chunks<NW, C, F, H, true>), dim3(grid), dim3(npad + 64), lds, cs,
                                (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, bnd, ce,
-                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, (int)c->cap, (int)c->halo, prov, limit, c->d_flow_err);
+                               a0_all, exact_chunk, c->n, c->d_L.p, (int)c->cap, (int)c->halo, prov, limit, c->d_flow_err);
         else
             hipLaunchKernelGGL((k_cansee_chunks<NW, C, F, H, false>), dim3(grid), dim3(npad + 64), lds, cs,
                                (const int4*)c->d_cdesc.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, bnd, ce,
-                               (int)pl.a[0], exact_chunk, c->n, c->d_L.p, (int)c->cap, (int)c->halo, prov, limit, c->d_flow_err);
+                               a0_all, exact_chunk, c->n, c->d_L.p, (int)c->cap, (int)c->halo, prov, limit, c->d_flow_err);
         c->ctr.kernel_launches++;
     };
-    sweep(pl.G * NCG, -1, 0u);
-    c->ctr.chunk_sweeps += pl.G;
-    for (int k = 1; k < pl.G; ++k) {
+    if (sweep_all) {
+        sweep(pl.G * NCG, -1, 0u);
+        c->ctr.chunk_sweeps += pl.G;
+    }
+    for (int k = k_from; k < k_to; ++k) {
         const int64_t len = pl.a[k + 1] - pl.a[k];
         // repair by gathers up to 1/32 of the chunk's entries, a second (dependent) sweep beyond (the sweep counts
         // provisional STORES of C columns each)
         const unsigned limit = (unsigned)std::min<int64_t>((len * c->n) / (32 * C), 0x7fffffff);
         const int blocks = (int)std::min<int64_t>((len + 3) / 4, 2048);
         hipLaunchKernelGGL(k_cansee_fixup<NW>, dim3(blocks), dim3(256), 0, cs, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
-                           bnd + (size_t)(2 * k) * npad, (int)pl.a[0], (int)pl.w[k], (int)pl.a[k], (int)pl.a[k + 1], c->n, c->d_L.p,
+                           bnd + (size_t)(2 * k) * npad, a0_all, (int)pl.w[k], (int)pl.a[k], (int)pl.a[k + 1], c->n, c->d_L.p,
                            (const unsigned*)(prov + k), limit, fixed);
         c->ctr.kernel_launches++;
         sweep(NCG, k, limit);
@@ -718,15 +700,24 @@ int launch_cansee_chunks_t(sw_ctx* c, int i) {
 }
 
 template <int NW>
-int launch_cansee_chunks(sw_ctx* c, int i) {
+int launch_cansee_plan(sw_ctx* c, const sw_ctx::ChunkPlan& pl, const int* bnd, unsigned* prov, unsigned* fixed,
+                       int a0_all, bool sweep_all, int k_from, int k_to) {
     if constexpr (NW <= 4) {
         switch (c->chunk_cfg) {
-            case 1: return launch_cansee_chunks_t<NW, 2, 8, 16>(c, i);
-            case 2: return launch_cansee_chunks_t<NW, 4, 4, 8>(c, i);
-            default: return launch_cansee_chunks_t<NW, 4, 8, 8>(c, i);
+            case 1: return launch_cansee_chunks_t<NW, 2, 8, 16>(c, pl, bnd, prov, fixed, a0_all, sweep_all, k_from, k_to);
+            case 2: return launch_cansee_chunks_t<NW, 4, 4, 8>(c, pl, bnd, prov, fixed, a0_all, sweep_all, k_from, k_to);
+            default: return launch_cansee_chunks_t<NW, 4, 8, 8>(c, pl, bnd, prov, fixed, a0_all, sweep_all, k_from, k_to);
         }
     }
     return fail(c, SW_EINVAL, "chunked sweep: more than 256 members");
+}
+
+// the chunked sweep of sub-batch i of the running sw_divide_rounds call
+template <int NW>
+int launch_cansee_chunks(sw_ctx* c, int i) {
+    const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
+    return launch_cansee_plan<NW>(c, pl, (const int*)c->d_cbnd.p + (size_t)pl.row0 * c->npad, c->d_prov + (size_t)i * SW_MAX_CHUNKS,
+                                  c->d_prov + (size_t)SW_PROV_ROWS * SW_MAX_CHUNKS + i, (int)pl.a[0], true, 1, pl.G);
 }
 
 template <int NW, int MPL, int F, int H>
@@ -1023,10 +1014,19 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     cut.push_back(first + K);
     const int S = (int)cut.size() - 1;
     const bool flow = c->cansee_impl >= 6;
+    // rows already in the table (event-range split: swept by sw_cansee_range or imported): no sweep, the round
+    // loop still waits for whatever the sweep stream has in flight (imports, repairs)
+    bool preswept = false;
+    for (const auto& pr : c->present) {
+        if (first >= pr.first && first + K <= pr.second) preswept = true;
+        else if (first < pr.second && first + K > pr.first)
+            return fail(c, SW_EINVAL, "divide_rounds [%lld, %lld) straddles the rows [%lld, %lld) already present (sw_cansee_range / sw_import_rows)",
+                        (long long)first, (long long)(first + K), (long long)pr.first, (long long)pr.second);
+    }
     std::vector<int> hmins(S), nlevs(S);
     int max_nlev = 1;
     int64_t max_k = 1;
-    if (!flow) {
+    if (!flow && !preswept) {
         CHK(ensure_dag_h(c));  // the level-bucketed kernels need the heights (swirld.py:117-120)
         for (int i = 0; i < S; ++i) {
             int hmax;
@@ -1076,11 +1076,11 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         HIPCHK(c, hipMemcpyAsync(bounds_h.data(), c->d_bounds.p, bounds_h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, cs));
         HIPCHK(c, hipStreamSynchronize(cs));
     }
-    if (!flow) HIPCHK(c, hipMemcpyAsync(c->d_prev_head.p, c->divided_head.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, cs));
     // ---- chunk plan: a sub-batch long enough is cut into G chunks that are swept concurrently, each from
     // `halo` events before its start (k_cansee_chunks); their chain positions come from one more search kernel
     c->chunk_plan.assign(S, sw_ctx::ChunkPlan{});
-    if (flow && np <= 256 && c->chunks > 1 && !c->chunks_off && !c->vm.active && S <= SW_PROV_ROWS) {
+    if (flow && !preswept && np <= 256 && c->chunks > 1 && !c->chunks_off && !c->vm.active && S <= SW_PROV_ROWS &&
+        c->d_L.cap >= table_elems(c, c->cap)) {   // (the halo scratch rows exist: they live behind the table's last row)
         std::vector<long long>& ccuts = c->ccuts_stage;
         ccuts.clear();
         int max_g = 0;
@@ -1115,7 +1115,9 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     for (int i = 0; i < S; ++i) {
         const int64_t a = cut[i], k = cut[i + 1] - cut[i];
         Span scs{};
-        if (flow && c->chunk_plan[i].G >= 2) {
+        if (preswept) {
+            scs = span_begin(c, cs);
+        } else if (flow && c->chunk_plan[i].G >= 2) {
             scs = span_begin(c, cs);
             CHK(launch_cansee_chunks<NW>(c, i));
         } else if (flow) {
@@ -1499,13 +1501,14 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     for (int i = 0; i < nr; ++i) {
         for (int m = 0; m < n; ++m) {
             const int hi = q[(size_t)i * np + m];
-            for (int p = ord[m]; p < hi; ++p) {
-                acc_ev.push_back(c->chain_ev_h[c->chain_start_h[m] + p]);
-                acc_ri.push_back(i);
+            if (hi > ord[m]) {
+                const int32_t* seg = c->chain_ev_h.data() + (size_t)c->chain_start_h[m];
+                acc_ev.insert(acc_ev.end(), seg + ord[m], seg + hi);
+                ord[m] = hi;
             }
-            if (hi > ord[m]) ord[m] = hi;
         }
         acc_off[i + 1] = (int64_t)acc_ev.size();
+        acc_ri.resize(acc_ev.size(), i);
     }
     const int64_t n_acc = (int64_t)acc_ev.size();
     lap("segments");
@@ -1525,12 +1528,54 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
             HIPCHK(c, hipMemcpyAsync(c->d_ordpos.p, op_.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
+        // A call that orders many events: the first-descendant table (k_order_firstdesc) instead of one binary
+        // search per (event, famous witness) pair.  Same samples, by construction and by test (SW_ORDER_BULK=<events>
+        // moves the threshold, 0 = never).
+        const int64_t bulk_min = getenv("SW_ORDER_BULK") ? atoll(getenv("SW_ORDER_BULK")) : 16384;   // (read per call: the tests force either path)
+        int64_t x0 = c->N, x1 = 0;
+        for (int m = 0; m < n; ++m)
+            if (ord[m] > c->ord_pos[m]) {
+                x0 = std::min<int64_t>(x0, c->chain_ev_h[(size_t)c->chain_start_h[m] + c->ord_pos[m]]);
+                x1 = std::max<int64_t>(x1, (int64_t)c->chain_ev_h[(size_t)c->chain_start_h[m] + ord[m] - 1] + 1);
+            }
+        // (a table beyond SW_ORDER_TMAX_MB [16384] is not built: the searches serve such a call)
+        const int64_t tmax = (getenv("SW_ORDER_TMAX_MB") ? atoll(getenv("SW_ORDER_TMAX_MB")) : 16384) << 20;
+        const bool bulk = bulk_min > 0 && n_acc >= bulk_min && (x1 - x0) * (int64_t)np * 4 <= tmax;
+        if (bulk) {
+            int64_t y1 = 0;
+            std::vector<int32_t> fw_cr(fw_ev.size());
+            for (size_t i = 0; i < fw_ev.size(); ++i) { fw_cr[i] = c->cr[fw_ev[i]]; y1 = std::max<int64_t>(y1, (int64_t)fw_ev[i] + 1); }
+            CHK(dgrow(c, c->d_fw_cr, std::max<size_t>(fw_cr.size(), 1), 0));
+            CHK(dgrow(c, c->d_fd, (size_t)(x1 - x0) * np, 0));
+            CHK(dgrow(c, c->d_ordhi, np, 0));
+            std::vector<int32_t> oh(np, 0);
+            std::copy(ord.begin(), ord.end(), oh.begin());
+            HIPCHK(c, hipMemcpyAsync(c->d_fw_cr.p, fw_cr.data(), fw_cr.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_ordhi.p, oh.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_fd.p, 0xff, (size_t)(x1 - x0) * np * sizeof(int32_t), c->stream));
+            const int ytile = 256;
+            const int64_t tiles = (y1 - x0 + ytile - 1) / ytile;
+            if (tiles > 0)
+                hipLaunchKernelGGL(k_order_firstdesc<NW>, dim3((unsigned)(tiles * 8)), dim3(256), 0, c->stream, (const int*)c->d_L.p,
+                                   (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
+                                   (const int*)c->d_chain_ev.p, (const int*)c->d_ordpos.p, (const int*)c->d_ordhi.p, (int)x0, (int)y1, (int)x0,
+                                   (int)c->first_resident, ytile, c->d_fd.p);
+            hipLaunchKernelGGL(k_order_times_fd<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
+                               (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
+                               (const int*)c->d_fw_cr.p, (const int*)c->d_fw_off.p, (const int*)c->d_fd.p, (int)x0,
+                               (const int*)c->d_sp.p, (const double*)c->d_t.p, np, c->d_ts.p, c->d_err);
+            c->ctr.kernel_launches += 2;
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging vectors above are locals)
+            // the table is as large as the can_see rows of the ordered range: given back when it is big
+            if (c->d_fd.cap * sizeof(int32_t) > ((size_t)256 << 20)) dfree(c->d_fd);
+        } else {
         hipLaunchKernelGGL(k_order_times<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
                            (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
                            (const int*)c->d_fw_off.p, (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_seq.p,
                            (const double*)c->d_t.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
                            (const int*)c->d_ordpos.p, np, c->d_ts.p, c->d_err);
         c->ctr.kernel_launches++;
+        }
         // device sort of every round's segment by (ts, first 8 whitened key bytes)
         CHK(dgrow(c, c->d_white, (size_t)nr * 64, 0));
         CHK(dgrow(c, c->d_acc_off, nr + 1, 0));
@@ -1568,11 +1613,11 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     std::vector<Item> items;
     for (int i = 0; i < nr; ++i) {
         if (!hostflag[i]) {  // sorted on the device
-            for (int64_t a = acc_off[i]; a < acc_off[i + 1]; ++a) {
-                c->transactions.push_back(sorted[a]);
-                if (out_events && produced < cap) out_events[produced] = sorted[a];
-                ++produced;
-            }
+            const int64_t cnt = acc_off[i + 1] - acc_off[i];
+            c->transactions.insert(c->transactions.end(), sorted.begin() + acc_off[i], sorted.begin() + acc_off[i + 1]);
+            if (out_events && produced < cap)
+                memcpy(out_events + produced, sorted.data() + acc_off[i], (size_t)std::min<int64_t>(cnt, cap - produced) * sizeof(int32_t));
+            produced += cnt;
             continue;
         }
         unsigned char white[64] = {0};  // swirld.py:285
@@ -1668,27 +1713,50 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         c->K = 12;
         c->skip = 10;
     }
-    if (const char* s = getenv("SW_TALLY_K")) c->K = std::max(1, std::min(63, atoi(s)));  // the candidate table has 64 columns
-    if (const char* s = getenv("SW_BAND")) c->NEARCAP = std::max(64, atoi(s));
-    if (const char* s = getenv("SW_BAND_MAX")) c->MCAP = std::max(64, atoi(s));
+    // Tuning / diagnostic switches (environment, read here once per context).  None changes results; every one is
+    // VALIDATED: a value that is not an integer inside the documented range fails sw_create with SW_EINVAL naming
+    // the variable, instead of being silently clamped or read as 0.
+    std::string knob_err;
+    auto knob = [&](const char* name, long long lo, long long hi, auto* dst) {
+        const char* s = getenv(name);
+        if (!s || !*s) return;
+        char* end = nullptr;
+        const long long v = strtoll(s, &end, 10);
+        if (*end != 0 || v < lo || v > hi) {
+            if (knob_err.empty()) { char b[160]; snprintf(b, sizeof b, "%s=%s: an integer in [%lld, %lld]", name, s, lo, hi); knob_err = b; }
+            return;
+        }
+        *dst = static_cast<std::remove_pointer_t<decltype(dst)>>(v);
+    };
+    int graph = c->use_graph ? 1 : 0;
+    knob("SW_TALLY_K", 1, 63, &c->K);             // (rounded to a multiple of 4 and capped at 60 below: a member's row of the candidate table has 64 columns)
+    knob("SW_BAND", 64, 1 << 28, &c->NEARCAP);
+    knob("SW_BAND_MAX", 64, 1 << 28, &c->MCAP);
     c->MCAP = std::max(c->MCAP, c->NEARCAP);
-    if (const char* s = getenv("SW_BATCH")) c->BATCH = std::max(1, atoi(s));
-    if (const char* s = getenv("SW_GRAPH")) c->use_graph = atoi(s) != 0;
-    if (const char* s = getenv("SW_BAND_BLOCKS")) c->band_blocks = std::max(1, std::min(4096, atoi(s)));
-    if (const char* s = getenv("SW_TALLY_PF")) c->tally_pf = atoi(s) != 0;
-    if (const char* s = getenv("SW_PIPE")) c->pipe = std::max(1, std::min(64, atoi(s)));
+    knob("SW_BATCH", 1, 4096, &c->BATCH);
+    knob("SW_GRAPH", 0, 1, &graph);
+    c->use_graph = graph != 0;
+    knob("SW_BAND_BLOCKS", 1, 4096, &c->band_blocks);
+    knob("SW_TALLY_PF", 0, 1, &c->tally_pf);
+    knob("SW_PIPE", 1, 64, &c->pipe);
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
-    if (const char* s = getenv("SW_CANSEE_IMPL")) c->cansee_impl = atoi(s);
-    if (const char* s = getenv("SW_TALLY_IMPL")) c->tally_impl = atoi(s);
-    if (const char* s = getenv("SW_FLOW_CFG")) c->flow_cfg = atoi(s);
-    if (const char* s = getenv("SW_CHUNKS")) c->chunks = std::max(1, std::min(SW_MAX_CHUNKS, atoi(s)));
-    if (const char* s = getenv("SW_CHUNK_CFG")) c->chunk_cfg = std::max(0, std::min(2, atoi(s)));
-    if (const char* s = getenv("SW_CHUNK_MIN")) c->chunk_min = std::max(64, atoi(s));
+    knob("SW_CANSEE_IMPL", 2, 6, &c->cansee_impl);
+    if (c->cansee_impl == 4 || c->cansee_impl == 5) knob_err = "SW_CANSEE_IMPL: 6 (dataflow sweep), 2 or 3 (level-bucketed sweep)";
+    knob("SW_TALLY_IMPL", 0, 1, &c->tally_impl);
+    knob("SW_FLOW_CFG", 0, 3, &c->flow_cfg);
+    knob("SW_CHUNKS", 1, SW_MAX_CHUNKS, &c->chunks);
+    knob("SW_CHUNK_CFG", 0, 2, &c->chunk_cfg);
+    knob("SW_CHUNK_MIN", 64, 1 << 30, &c->chunk_min);
     c->halo = 32 * (int64_t)c->npad;
-    if (const char* s = getenv("SW_HALO")) c->halo = std::max(0, atoi(s));
-    if (const char* s = getenv("SW_ELECT_IMPL")) c->elect_impl = atoi(s);
-    if (const char* s = getenv("SW_GALLOP")) c->gallop_after = std::max(0, atoi(s));
-    if (const char* s = getenv("SW_SKIP")) c->skip = std::max(0, std::min(32, atoi(s)));
+    knob("SW_HALO", 0, 1 << 24, &c->halo);
+    knob("SW_ELECT_IMPL", 0, 1, &c->elect_impl);
+    knob("SW_GALLOP", 0, 255, &c->gallop_after);
+    knob("SW_SKIP", 0, 32, &c->skip);
+    knob("SW_RING_H", 0, 64, &c->ring_H_req);      // ring depth of the level-bucketed sweep (0 = automatic)
+    if (!knob_err.empty()) {
+        delete c;
+        return fail(nullptr, SW_EINVAL, "%s", knob_err.c_str());
+    }
     c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
     if (c->debug_timing) {
         if (hipMalloc(&c->d_flow_dbg, 8 * sizeof(u64)) != hipSuccess) c->d_flow_dbg = nullptr;
@@ -1699,15 +1767,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         else (void)hipMemset(c->d_dbg, 0, (size_t)SW_DBG_MAX_ITERS * 32 * 8);
     }
     c->nev.assign(n_members, 0);
-    {
-        // LDS ring depth of the can_see kernel: largest power of two <= 8 that fits 144 KiB
-        const size_t per_slot = ((size_t)c->npad * 16 + c->npad) * sizeof(int);
-        int H = 8;
-        while (H > 1 && per_slot * H > 144u * 1024u) H >>= 1;
-        if (per_slot * H > 144u * 1024u) H = 0;
-        if (const char* s = getenv("SW_RING_H")) { int v = atoi(s); c->ring_H_req = v; if (v >= 1 && v <= H && (v & (v - 1)) == 0) H = v; }
-        c->ring_H = H;
-    }
     c->BATCH = (c->BATCH + 1) & ~1;  // even: the loop state is double-buffered by iteration parity
     // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway); a member's row of the candidate
     // table has 64 slots and slot 0 is the window header, so at most 60 candidates after rounding
@@ -1783,7 +1842,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CHIP(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
     CHIP(hipEventCreateWithFlags(&c->ev_cs_done, hipEventDisableTiming));
     CHIP(hipEventCreateWithFlags(&c->ev_main_mark, hipEventDisableTiming));
-    CCHK(dgrow(c, c->d_prev_head, 2 * np, 0));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_chain_start, np, 0));
     CCHK(dgrow(c, c->d_chain_cnt, np, 0));
@@ -1800,15 +1858,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CHIP(hipMemsetAsync(c->d_found64.p, 0xff, 2 * np * sizeof(u64), c->stream));
     CHIP(hipMemsetAsync(c->d_unres.p, 0, 2 * np * sizeof(int32_t), c->stream));
     CCHK(ensure_rounds(c, 256));
-    if (c->ring_H >= 1) {
-        const size_t lds = ((size_t)np * c->ring_H * 16 + (size_t)np * c->ring_H) * sizeof(int);
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute((const void*)k_cansee_ring<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            while (c->ring_H > 1 && ((size_t)np * c->ring_H * 17) * sizeof(int) > 48 * 1024) c->ring_H >>= 1;
-            if (((size_t)np * c->ring_H * 17) * sizeof(int) > 48 * 1024) c->cansee_impl = 0;
-        }
-    }
     CHIP(hipStreamSynchronize(c->stream));
 #undef CCHK
 #undef CHIP
@@ -1840,7 +1889,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->x_white); dfree(c->x_times); dfree(c->x_tsort); dfree(c->x_items_ts); dfree(c->x_hdr);
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
-    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_prev_head); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
@@ -1852,6 +1901,10 @@ int sw_destroy(sw_ctx* c) {
     if (c->d_err) (void)hipFree(c->d_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
     dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_acc_off); dfree(c->d_white);
+    dfree(c->d_fw_cr); dfree(c->d_fd); dfree(c->d_ordhi);
+    dfree(c->d_rbnd); dfree(c->d_rcuts);
+    if (c->d_rprov) (void)hipFree(c->d_rprov);
+    if (c->ev_user) (void)hipEventDestroy(c->ev_user);
     for (int g = 0; g < 3; ++g) {
         if (c->loop_exec[g]) (void)hipGraphExecDestroy(c->loop_exec[g]);
         if (c->loop_graph[g]) (void)hipGraphDestroy(c->loop_graph[g]);
@@ -2472,6 +2525,179 @@ int sw_commit_fame(sw_ctx* c, const int8_t* famous, const uint8_t* decided, int 
     return SW_OK;
 }
 
+// ---- multi-GPU split of the can_see table by event ranges -----------------------
+static int range_checks(sw_ctx* c, int64_t first, int64_t K, const char* what) {
+    if (!c) return SW_EINVAL;
+    if (c->poisoned) return fail(c, SW_EIO, "context unusable after an earlier device failure");
+    if (c->exact) return fail(c, SW_ENOTSUP, "%s is not available on the exact (forked-hashgraph) path", what);
+    if (c->vm.active) return fail(c, SW_ENOTSUP, "%s is not available with the windowed table", what);
+    if (c->npad > 256 || c->cansee_impl != 6) return fail(c, SW_ENOTSUP, "%s needs the chunk-parallel dataflow sweep (at most 256 members)", what);
+    if (first < 0 || K <= 0 || first + K > c->N) return fail(c, SW_ERANGE, "%s: events [%lld, %lld) outside the stored hashgraph", what, (long long)first, (long long)(first + K));
+    if (first < c->divided) return fail(c, SW_EINVAL, "%s: events below %lld are divided already", what, (long long)c->divided);
+    return SW_OK;
+}
+
+static void mark_present(sw_ctx* c, int64_t a, int64_t b) {
+    c->present.push_back({a, b});
+    std::sort(c->present.begin(), c->present.end());
+    std::vector<std::pair<int64_t, int64_t>> m;
+    for (const auto& pr : c->present) {
+        if (!m.empty() && pr.first <= m.back().second) m.back().second = std::max(m.back().second, pr.second);
+        else m.push_back(pr);
+    }
+    c->present.swap(m);
+}
+
+int sw_row_stride(const sw_ctx* c) { return c ? c->npad : 0; }
+
+}  // extern "C"
+template <int NW>
+static int do_cansee_range(sw_ctx* c, int64_t first, int64_t K) {
+    const int np = c->npad;
+    if ((int)c->ranges.size() >= SW_RANGE_SLOTS) return fail(c, SW_ERANGE, "more than %d ranges between two rewinds", SW_RANGE_SLOTS);
+    for (const auto& pr : c->present)
+        if (first < pr.second && first + K > pr.first) return fail(c, SW_EINVAL, "sw_cansee_range: rows [%lld, %lld) are present already", (long long)pr.first, (long long)pr.second);
+    if (!c->d_rprov) {
+        HIPCHK(c, hipMalloc((void**)&c->d_rprov, (size_t)SW_RANGE_SLOTS * (SW_MAX_CHUNKS + 1) * sizeof(unsigned)));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_user, hipEventDisableTiming));
+    }
+    if (c->d_L.cap < table_elems(c, c->cap)) return fail(c, SW_EIO, "the can_see table has no halo scratch rows (internal)");
+    sw_ctx::RangeRec r;
+    r.first = first; r.K = K;
+    r.slot = (int)c->ranges.size();
+    r.row0 = r.slot * (2 * SW_MAX_CHUNKS + 2);
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->chunks, K / std::max<int64_t>(c->chunk_min, 1)));
+    r.pl.G = G;
+    std::vector<long long>& cc = c->rcuts_stage;
+    cc.assign((size_t)2 * SW_MAX_CHUNKS + 2, first + K);
+    for (int k = 0; k <= G; ++k) r.pl.a[k] = first + K * k / G;
+    for (int k = 0; k < G; ++k) {
+        r.pl.w[k] = std::max<int64_t>(0, r.pl.a[k] - c->halo);   // chunk 0 has a halo too: nothing below the range is here yet
+        cc[2 * k] = r.pl.w[k];
+        cc[2 * k + 1] = r.pl.a[k];
+    }
+    cc[2 * G] = cc[2 * G + 1] = r.pl.a[G];
+    hipStream_t cs = c->stream_cs;
+    // behind whatever the main stream still has in flight (appends return without a host synchronisation)
+    HIPCHK(c, hipEventRecord(c->ev_main_mark, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(cs, c->ev_main_mark, 0));
+    CHK(dgrow(c, c->d_rcuts, (size_t)SW_RANGE_SLOTS * (2 * SW_MAX_CHUNKS + 2), 0));
+    CHK(dgrow(c, c->d_rbnd, (size_t)SW_RANGE_SLOTS * (2 * SW_MAX_CHUNKS + 2) * np, 0));
+    HIPCHK(c, hipMemcpyAsync(c->d_rcuts.p + r.row0, cc.data(), cc.size() * sizeof(long long), hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipStreamSynchronize(cs));   // (one staging vector per context: reusable on return)
+    hipLaunchKernelGGL(k_chain_bounds, dim3((unsigned)cc.size()), dim3(np), 0, cs, (const int*)c->d_chain_start.p,
+                       (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, (const long long*)(c->d_rcuts.p + r.row0), np,
+                       c->d_rbnd.p + (size_t)r.row0 * np);
+    unsigned* prov = c->d_rprov + (size_t)r.slot * (SW_MAX_CHUNKS + 1);
+    HIPCHK(c, hipMemsetAsync(prov, 0, (SW_MAX_CHUNKS + 1) * sizeof(unsigned), cs));
+    c->ctr.kernel_launches++;
+    CHK(launch_cansee_plan<NW>(c, r.pl, (const int*)c->d_rbnd.p + (size_t)r.row0 * np, prov, prov + SW_MAX_CHUNKS, 0, true, 0, 0));
+    c->ranges.push_back(r);
+    mark_present(c, first, first + K);
+    return SW_OK;
+}
+
+extern "C" {
+int sw_cansee_range(sw_ctx* c, int64_t first, int64_t K) {
+    CHK(range_checks(c, first, K, "sw_cansee_range"));
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_events(c, c->N));
+    switch (c->nw) {
+        case 1: return do_cansee_range<1>(c, first, K);
+        case 2: return do_cansee_range<2>(c, first, K);
+        case 4: return do_cansee_range<4>(c, first, K);
+    }
+    return fail(c, SW_ENOTSUP, "sw_cansee_range: more than 256 members");
+}
+
+int sw_cansee_repair(sw_ctx* c, int64_t first, int64_t K) {
+    CHK(range_checks(c, first, K, "sw_cansee_repair"));
+    HIPCHK(c, hipSetDevice(c->device));
+    for (auto& r : c->ranges) {
+        if (r.first != first || r.K != K) continue;
+        if (r.repaired) return SW_OK;
+        // every row below the range must be here: the repair reads the rows the provisional entries name
+        int64_t covered = c->divided;
+        for (const auto& pr : c->present) if (pr.first <= covered) covered = std::max(covered, pr.second);
+        if (covered < first) return fail(c, SW_EINVAL, "sw_cansee_repair: the rows [%lld, %lld) below the range are not present yet", (long long)covered, (long long)first);
+        const int np = c->npad;
+        unsigned* prov = c->d_rprov + (size_t)r.slot * (SW_MAX_CHUNKS + 1);
+        const int k_from = r.pl.w[0] > 0 ? 0 : 1;   // (a range that starts at event 0 has no halo in front of its first chunk)
+        int rc = SW_EINVAL;
+        switch (c->nw) {
+            case 1: rc = launch_cansee_plan<1>(c, r.pl, (const int*)c->d_rbnd.p + (size_t)r.row0 * np, prov, prov + SW_MAX_CHUNKS, 0, false, k_from, r.pl.G); break;
+            case 2: rc = launch_cansee_plan<2>(c, r.pl, (const int*)c->d_rbnd.p + (size_t)r.row0 * np, prov, prov + SW_MAX_CHUNKS, 0, false, k_from, r.pl.G); break;
+            case 4: rc = launch_cansee_plan<4>(c, r.pl, (const int*)c->d_rbnd.p + (size_t)r.row0 * np, prov, prov + SW_MAX_CHUNKS, 0, false, k_from, r.pl.G); break;
+        }
+        CHK(rc);
+        r.repaired = true;
+        return SW_OK;
+    }
+    return fail(c, SW_EINVAL, "sw_cansee_repair: [%lld, %lld) is not a range swept by sw_cansee_range", (long long)first, (long long)(first + K));
+}
+
+int sw_export_rows(sw_ctx* c, int64_t first, int64_t K, void* dst_device, void* user_stream) {
+    if (!c || !dst_device) return SW_EINVAL;
+    if (c->exact || c->vm.active) return fail(c, SW_ENOTSUP, "sw_export_rows: fast path with the plain table only");
+    if (first < 0 || K <= 0 || first + K > c->N) return fail(c, SW_ERANGE, "sw_export_rows: events [%lld, %lld) outside the stored hashgraph", (long long)first, (long long)(first + K));
+    bool ok = first + K <= c->divided;
+    for (const auto& pr : c->present) ok = ok || (first >= pr.first && first + K <= pr.second);
+    if (!ok) return fail(c, SW_EINVAL, "sw_export_rows: the rows [%lld, %lld) have not been computed here", (long long)first, (long long)(first + K));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->ev_user) HIPCHK(c, hipEventCreateWithFlags(&c->ev_user, hipEventDisableTiming));
+    hipStream_t cs = c->stream_cs, us = (hipStream_t)user_stream;
+    // the destination may still be read by work the caller enqueued earlier (a previous collective)
+    HIPCHK(c, hipEventRecord(c->ev_user, us));
+    HIPCHK(c, hipStreamWaitEvent(cs, c->ev_user, 0));
+    HIPCHK(c, hipMemcpyAsync(dst_device, c->d_L.p + (size_t)first * c->npad, (size_t)K * c->npad * sizeof(int32_t), hipMemcpyDeviceToDevice, cs));
+    HIPCHK(c, hipEventRecord(c->ev_user, cs));
+    HIPCHK(c, hipStreamWaitEvent(us, c->ev_user, 0));
+    return SW_OK;
+}
+
+int sw_import_rows(sw_ctx* c, int64_t first, int64_t K, const void* src_device, void* user_stream) {
+    if (!src_device) return SW_EINVAL;
+    CHK(range_checks(c, first, K, "sw_import_rows"));
+    for (const auto& pr : c->present)
+        if (first < pr.second && first + K > pr.first) return fail(c, SW_EINVAL, "sw_import_rows: rows [%lld, %lld) are present already", (long long)pr.first, (long long)pr.second);
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_events(c, c->N));
+    if (!c->ev_user) HIPCHK(c, hipEventCreateWithFlags(&c->ev_user, hipEventDisableTiming));
+    hipStream_t cs = c->stream_cs, us = (hipStream_t)user_stream;
+    HIPCHK(c, hipEventRecord(c->ev_user, us));            // what the caller enqueued so far (the collective that fills src)
+    HIPCHK(c, hipStreamWaitEvent(cs, c->ev_user, 0));
+    HIPCHK(c, hipMemcpyAsync(c->d_L.p + (size_t)first * c->npad, src_device, (size_t)K * c->npad * sizeof(int32_t), hipMemcpyDeviceToDevice, cs));
+    HIPCHK(c, hipEventRecord(c->ev_user, cs));            // ... and the caller's stream may not reuse src before the copy is done
+    HIPCHK(c, hipStreamWaitEvent(us, c->ev_user, 0));
+    mark_present(c, first, first + K);
+    return SW_OK;
+}
+
+int sw_get_range_stats(sw_ctx* c, int64_t* provisional, int64_t* repaired, int64_t* resweeps) {
+    if (!c) return SW_EINVAL;
+    int64_t pv = 0, rp = 0, rs = 0;
+    if (c->d_rprov && !c->ranges.empty()) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream_cs));
+        std::vector<unsigned> h((size_t)SW_RANGE_SLOTS * (SW_MAX_CHUNKS + 1));
+        HIPCHK(c, hipMemcpy(h.data(), c->d_rprov, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (const auto& r : c->ranges) {
+            const unsigned* p = h.data() + (size_t)r.slot * (SW_MAX_CHUNKS + 1);
+            const int Cc = c->chunk_cfg == 1 ? 2 : 4;
+            for (int k = 0; k < r.pl.G; ++k) {
+                pv += p[k];
+                const int64_t len = r.pl.a[k + 1] - r.pl.a[k];
+                if ((k > 0 || r.pl.w[0] > 0) && p[k] > (unsigned)std::min<int64_t>((len * c->n) / (32 * Cc), 0x7fffffff)) ++rs;
+            }
+            rp += p[SW_MAX_CHUNKS];
+        }
+    }
+    if (provisional) *provisional = pv;
+    if (repaired) *repaired = rp;
+    if (resweeps) *resweeps = rs;
+    return SW_OK;
+}
+
 int sw_set_window(sw_ctx* c, int enable, int chunk_mb) {
     if (!c) return SW_EINVAL;
     if (c->N != 0) return fail(c, SW_EINVAL, "sw_set_window must be called before the first event is appended");
@@ -2481,7 +2707,7 @@ int sw_set_window(sw_ctx* c, int enable, int chunk_mb) {
             HIPCHK(c, hipDeviceSynchronize());
             vm_destroy(c);
             c->d_L.p = nullptr; c->d_L.cap = 0;
-            if (c->cap) CHK(dgrow(c, c->d_L, (size_t)c->cap * c->npad, 0));
+            if (c->cap) CHK(dgrow(c, c->d_L, table_elems(c, c->cap), 0));   // (with the halo scratch rows: ADVICE r3)
         }
         return SW_OK;
     }
@@ -2611,6 +2837,8 @@ int sw_rewind(sw_ctx* c) {
         c->first_resident = 0;
         CHK(vm_ensure(c, (size_t)c->N * c->npad * sizeof(int32_t)));
     }
+    c->ranges.clear();
+    c->present.clear();
     std::fill(c->divided_head.begin(), c->divided_head.end(), -1);
     std::fill(c->lo0_h.begin(), c->lo0_h.end(), SW_INF);
     std::fill(c->cons_h.begin(), c->cons_h.end(), 0);

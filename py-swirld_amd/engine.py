@@ -255,6 +255,36 @@ class Hashgraph:
         self._chk(self._L.sw_get_window(self._h, C.byref(a), C.byref(b), C.byref(e)))
         return int(a.value), int(b.value), int(e.value)
 
+    # ---- multi-GPU split of the can_see table by event ranges (include/swirld_hip.h) ----
+    @property
+    def row_stride(self):
+        """int32 elements per can_see row on the device (members padded to a multiple of 64)."""
+        return int(self._L.sw_row_stride(self._h))
+
+    def cansee_range(self, first, K):
+        """Sweep the can_see rows of [first, first + K) from a halo (asynchronous); rows below the halo are leaves."""
+        self._chk(self._L.sw_cansee_range(self._h, int(first), int(K)))
+
+    def cansee_repair(self, first, K):
+        """Repair the provisional entries of a swept range from the (imported) final rows below it; device-gated."""
+        self._chk(self._L.sw_cansee_repair(self._h, int(first), int(K)))
+
+    def export_rows(self, first, K, dst_ptr, stream=0):
+        """Copy rows [first, first + K) to DEVICE memory at `dst_ptr` (K * row_stride int32); `stream` (a raw
+        hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) is made to wait for the copy."""
+        self._chk(self._L.sw_export_rows(self._h, int(first), int(K), C.c_void_p(int(dst_ptr)), C.c_void_p(int(stream))))
+
+    def import_rows(self, first, K, src_ptr, stream=0):
+        """Copy rows [first, first + K) from DEVICE memory at `src_ptr` into the table, after what `stream` has
+        enqueued so far; sw_divide_rounds will not sweep them."""
+        self._chk(self._L.sw_import_rows(self._h, int(first), int(K), C.c_void_p(int(src_ptr)), C.c_void_p(int(stream))))
+
+    def range_stats(self):
+        """(provisional entries counted by the range sweeps, entries changed by the repairs, ranges swept twice)."""
+        a, b, e = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._L.sw_get_range_stats(self._h, C.byref(a), C.byref(b), C.byref(e)))
+        return int(a.value), int(b.value), int(e.value)
+
     def rewind(self):
         """Forget all voting state; the ingested events stay resident (bench utility)."""
         self._chk(self._L.sw_rewind(self._h))

@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-REF_DIR = "/root/reference"
+REF_DIR = os.environ.get("SWIRLD_REFERENCE_PATH", "/root/reference")
 _STANDIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pysodium_standin")
 
 

@@ -11,8 +11,11 @@ pytestmark = pytest.mark.gpu
 FORKFREE = [n for n in golden_names() if "forks" not in n]
 
 
+@pytest.mark.parametrize("bulk", ["default", "1"])   # "1": every call through the first-descendant table (k_order_firstdesc)
 @pytest.mark.parametrize("name", FORKFREE)
-def test_find_order_matches_reference_golden(pkg, name):
+def test_find_order_matches_reference_golden(pkg, name, bulk, monkeypatch):
+    if bulk != "default":
+        monkeypatch.setenv("SW_ORDER_BULK", bulk)
     g = load_golden(name)
     h = pkg.Hashgraph(g["n"], g["stake"])
     calls = 0
@@ -32,8 +35,11 @@ def test_find_order_matches_reference_golden(pkg, name):
     (4, 4000, 81, 0, 0, 0, 9), (16, 12000, 82, 2, 0.25, 0.03, 500), (64, 40000, 83, 0, 0, 0, None),
     (64, 20000, 84, 3, 0.6, 0, 3000), (130, 20000, 85, 0, 0, 0, None), (256, 30000, 86, 0, 0, 0, 10000),
 ])
-def test_find_order_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk):
+@pytest.mark.parametrize("bulk", ["default", "1", "0"])   # default threshold, always the table, always the searches
+def test_find_order_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk, bulk, monkeypatch):
     from oracle.oracle import Oracle
+    if bulk != "default":
+        monkeypatch.setenv("SW_ORDER_BULK", bulk)
     cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
     t = t + (np.arange(N) % 7) * 0.25  # non-monotone timestamps with ties in the medians
     o, h = Oracle(n), pkg.Hashgraph(n)

@@ -253,12 +253,10 @@ def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
             h.close()
 
 
-@pytest.mark.parametrize("cansee,tally,ring_h", [("0", "0", None), ("1", "0", "1"), ("1", "1", "2"), ("0", "1", None),
-                                                 ("2", "1", None), ("2", "1", "1"), ("3", "1", "2"), ("3", "0", None),
-                                                 ("4", "1", None), ("4", "1", "1"), ("4", "0", "4"),
-                                                 ("5", "1", None), ("5", "0", "32"), ("6", "1", None), ("6", "0", None)])
+@pytest.mark.parametrize("cansee,tally,ring_h", [("2", "1", None), ("2", "1", "1"), ("2", "0", "4"), ("3", "1", "2"), ("3", "0", None),
+                                                 ("6", "1", None), ("6", "0", None)])
 def test_kernel_variants_agree(pkg, monkeypatch, cansee, tally, ring_h):
-    """Both can_see kernels (global-memory levels / LDS ring at several depths) and both
+    """Both can_see sweeps (level-bucketed with its LDS ring at several depths / dataflow) and both
     tally kernels (column-lane / bit-sliced) against the oracle, on inputs that stress the
     ring (stale other-parents miss it; incremental batches read rows of earlier kernels)."""
     monkeypatch.setenv("SW_CANSEE_IMPL", cansee)

@@ -79,3 +79,27 @@ def test_window_must_be_set_before_the_first_append(pkg):
     h.divide_rounds(0, 4)
     assert list(h.rounds()) == [0, 0, 0, 0]
     h.close()
+
+
+def test_window_off_after_reserve_keeps_the_halo_scratch_rows(pkg, monkeypatch):
+    """set_window(1) -> reserve -> set_window(0) re-allocated the table WITHOUT the scratch rows the
+    chunk-parallel sweep writes behind the last row; a divide of >= 2 chunks then wrote out of bounds.  One
+    helper sizes the table now; the run must use the chunked sweep and equal the oracle."""
+    from oracle.oracle import Oracle
+    n, N = 64, 80000
+    monkeypatch.setenv("SW_CHUNK_MIN", "2048")   # (sub-batches of ~19 k events: four chunks each)
+    stream = pkg.synth_hashgraph(n, N, 707)
+    h = pkg.Hashgraph(n)
+    h.set_window(True)
+    h.reserve(N)
+    h.set_window(False)
+    h.append_events(*stream)
+    c0 = h.counters()
+    h.divide_rounds(0, N)
+    assert h.counters()["chunk_sweeps"] > c0["chunk_sweeps"], "the chunk-parallel sweep did not run"
+    o = Oracle(n)
+    o.append_events(*stream)
+    o.divide_rounds(0, N)
+    assert np.array_equal(h.rounds(), o.round)
+    assert np.array_equal(h.can_see(N - 3000, 3000), o.can_see[N - 3000:])
+    h.close()

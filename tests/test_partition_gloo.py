@@ -73,7 +73,7 @@ def test_partitioned_fame_two_ranks_over_gloo(pkg):
         assert len(new_c) > 3
 
 
-def test_partition_helpers_and_cost_model(pkg):
+def test_partition_helpers(pkg):
     part = importlib.import_module("py-swirld_amd.partition")
     assert part.candidate_rounds(3, 10, 1, 3) == [4, 7]
     owned = sorted(r for p in range(4) for r in part.candidate_rounds(2, 17, p, 4))
@@ -82,6 +82,4 @@ def test_partition_helpers_and_cost_model(pkg):
     b = (np.array([[-1, -1], [0, 1]], np.int8), np.array([0, 1], np.uint8))
     fam, dec = part.merge_fame_tables([a, b])
     assert fam.tolist() == [[1, -1], [0, 1]] and dec.tolist() == [1, 1]
-    m = part.cost_model()
-    # the model's point: no variant buys a meaningful strong-scaling speed-up of the 1 M-event pass
-    assert m["best_speedup"] < 1.1 and m["can_see_sharded_ms"] > m["single_gpu_ms"]
+    assert part.chunk_cuts(0, 10, 3) == [0, 3, 6, 10] and part.chunk_cuts(5, 9, 2) == [5, 7, 9]
