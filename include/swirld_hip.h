@@ -22,6 +22,7 @@
 #ifndef SWIRLD_HIP_H
 #define SWIRLD_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -233,6 +234,9 @@ typedef struct sw_counters {
     int64_t chunk_resweeps;      /* chunks swept a second time from final rows (too many to repair)      */
 } sw_counters;
 int sw_get_counters(sw_ctx* ctx, sw_counters* out);
+/* The same for a caller built against another version of this header: copies min(out_bytes, sizeof(sw_counters))
+ * bytes (fields are only ever appended), so a shorter struct is never overrun and a longer one keeps its tail. */
+int sw_get_counters_sized(sw_ctx* ctx, void* out, size_t out_bytes);
 
 /* Per-phase GPU time of the most recent divide_rounds / decide_fame call, measured with
  * hipEvents on the context's own stream (ms).  Enabled by sw_set_profiling(ctx, 1). */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "sw_num_ordered": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sw_get_transactions": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "sw_get_counters": (C.c_int, [_P, C.POINTER(Counters)]),
+    "sw_get_counters_sized": (C.c_int, [_P, _P, C.c_size_t]),
     "sw_set_profiling": (C.c_int, [_P, C.c_int]),
     "sw_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "sw_debug_clocks": (C.c_int, [_P, _P, C.c_int64]),

@@ -960,6 +960,7 @@ struct LoopBufs {
                       // slot j (chain position cursor + j * stride); -1 = none
     int* gallop;      // [2][npad] window stride (bits 0-7; 1 = contiguous) and consecutive windows without
                       // a passing candidate (bits 8+) of the member in the current round
+    int* treecnt;     // [npad] tallies evaluated for the member in this run (k_tally_tree: one workgroup owns a member; read back with the loop state)
     int* front;       // [npad] per member the last round r with lo[r][member] finite (-1 none): where the next call resumes
     u64* dbg;         // diagnostics (SW_DEBUG_CLOCKS=1): [iteration][32] wall-clock stamps, else null
 };
@@ -987,7 +988,7 @@ __device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v));
 __global__ void __launch_bounds__(1024)
 k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len) {
     // chain lengths visible to this run = the sub-batch's row of the cut table (already on the device)
-    for (int i = threadIdx.x; i < npad; i += blockDim.x) chain_len[i] = visible_len[i];
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) { chain_len[i] = visible_len[i]; B.treecnt[i] = 0; }
     if (threadIdx.x == 0) {
         RState t{};
         t.r = r_start;
@@ -1014,7 +1015,8 @@ __global__ void __launch_bounds__(1024)
 k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
-               const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb) {
+               const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb,
+               int pf_pre, int n_rows) {
     __shared__ int s_red[2][4][16];  // [parity][quantity][wave]: per-wave partial results
     __shared__ int s_thr[1024];
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
@@ -1027,6 +1029,43 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
     pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
+    pin_arg(pf_pre); pin_arg(n_rows);
+    // BAND-ROW PREFETCH (pf_pre > 0: the launch has one extra wave per workgroup).  The band phase below is one burst of
+    // row reads behind ~4 us of resolve step; the band of this iteration is, to 70-80 %, the previous one shifted by one
+    // round.  So while the member threads resolve, the extra wave touches the rows its workgroup's band waves will most
+    // likely read — the previous band plus `pf_pre` events, dealt to waves by ABSOLUTE groups of 8 events (group g belongs
+    // to band wave g mod nwaves, whatever the band) — one 128-byte line per lane, nothing waited for: the rows are in
+    // this XCD's L2 when the band waves ask for them.  The wave ends before the first barrier (ended waves are not counted).
+    const int nthr = (int)blockDim.x - (pf_pre > 0 ? 64 : 0);   // member / band threads of this workgroup
+    if (pf_pre > 0 && (int)threadIdx.x >= nthr) {
+        const RState* sp_ = B.st + par;
+        const int p_done = sp_->done, p_mlo = sp_->mlo, p_mhi = sp_->mhi, p_iter = sp_->iter;
+        const int skipw_ = gridDim.x > 1 ? 1 : 0;
+        if (p_done || p_iter == 0 || (skipw_ && blockIdx.x == 0)) return;
+        const int wpb_ = nthr >> 6;
+        const int nwaves_ = ((int)gridDim.x - skipw_) * wpb_;
+        const int lane_ = (int)threadIdx.x & 63;
+        int hi_ = p_mhi + pf_pre;
+        hi_ = hi_ < n_rows ? hi_ : n_rows;
+        const int g_lo = p_mlo >> 3;
+        int dummy = 0;
+        for (int wv = 0; wv < wpb_; ++wv) {
+            const int wave_ = ((int)blockIdx.x - skipw_) * wpb_ + wv;
+            int g = g_lo + ((wave_ - g_lo) % nwaves_ + nwaves_) % nwaves_;   // first group >= g_lo of this band wave
+            for (int rep = 0; rep < 2; ++rep, g += nwaves_) {
+                const int k = g * 8 + (lane_ >> 3);          // 8 rows of 8 lines (npad = 256) ...
+                if (k < hi_) {
+                    // ... in general: a row is npad * 4 / 128 lines; lane l takes line (l & 7) + 8 i of row l >> 3
+                    for (int ln = lane_ & 7; ln < npad / 32; ln += 8) {
+                        const char* q = reinterpret_cast<const char*>(L) + ((size_t)k * npad * 4 + (size_t)ln * 128);
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(q) : "memory");
+                    }
+                }
+            }
+        }
+        asm volatile("" ::"v"(dummy));
+        return;
+    }
     const RState* si = B.st + par;
     RState* so = B.st + (1 - par);
     const bool writer = blockIdx.x == 0;
@@ -1177,7 +1216,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             }
         }
     }
-    const int rl = c & 63, rw = c >> 6, nwv = blockDim.x >> 6;
+    const int rl = c & 63, rw = c >> 6, nwv = nthr >> 6;
     int nun = 0;
     {   // count(un) and any(grow) with one barrier
         const u64 bu = __ballot(un != 0), bg = __ballot(grow != 0);
@@ -1363,7 +1402,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     if (B.dbg && stamp && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb + 7] = (u64)(need_mask ? mhi - mask_from : 0);
     if (done || !need_mask) { flush_cand(); return; }
     const int lane = lane_id();
-    const int wpb = blockDim.x >> 6;
+    const int wpb = nthr >> 6;
     // the writer block finishes later than the others (it publishes the state): it takes no
     // share of the band, so that the kernel ends with the band and not with its stores
     const int skipw = gridDim.x > 1 ? 1 : 0;
@@ -1373,13 +1412,15 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     int t_[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) t_[j] = s_thr[j * 64 + lane];
-    // a wave takes 8 consecutive band events per pass: the "is it a possible hop" test for all 8
-    // in one coalesced load, then the rows of up to four valid events in flight at once
-    for (int base = mask_from + wave * 8; base < mhi; base += nwaves * 8) {
+    // a wave takes the groups of 8 consecutive events g = wave (mod nwaves), by ABSOLUTE event index (what the
+    // prefetch wave assumed), the rows of up to RIF events in flight at once
+    const int g_first = mask_from >> 3;
+    for (int g = g_first + ((wave - g_first) % nwaves + nwaves) % nwaves; g * 8 < mhi; g += nwaves) {
         // (masks are built for every band event: testing "can it be a hop at all" first would
         // cost a dependent load, an unused mask costs 1 KB of row traffic)
+        const int base = g * 8;
         const int kk = base + (lane & 7);
-        u64 vm = __ballot(lane < 8 && kk < mhi);
+        u64 vm = __ballot(lane < 8 && kk < mhi && kk >= mask_from);
         constexpr int RIF = NW <= 4 ? 8 : 4;  // rows in flight per wave (one memory round trip per pass)
         while (vm) {
             int ks[RIF];
@@ -1879,6 +1920,192 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         }
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }
+    asm volatile("" ::"v"(pf_dummy));   // (the touch's destination register stays reserved to the end)
+    SW_STAMP(stamp, it_, sb + 5);
+}
+
+// ---------------------------------------------------------------------------------
+// Round loop, step 3, TREE form (SW_TALLY_IMPL=2): ONE workgroup of 8 waves per member searches the member's
+// window of K candidates in two dependent levels instead of evaluating every slot.
+// SS_r is monotone along a chain, so a FAILING slot rules out every slot before it:
+//   level 1   wave w evaluates slot (w + 1) s - 1, s = ceil(K / 8) (the last one clipped to the window);
+//   level 2   the first level-1 slot q that did not fail brackets the answer in (q - s, q]: the <= s - 1 slots in
+//             between are evaluated by as many waves; the first of them that does not fail — else q — is the
+//             member's verdict (PASS: its first event of round r + 1 in this window; FAR: decided by inheritance
+//             in k_resolve_band), and every slot before it is known to be false.
+// Against k_tally_bits (one wave per slot, K = 28: 7168 waves): 8 + 3 evaluations per member instead of 28, 2 waves per
+// SIMD instead of 7 (room for the concurrent sweep, 2.5x less L2 gather traffic), a 256-workgroup launch, and
+// the verdict is ONE plain store per member — no atomics at all (they serialise at ~12 ns each per cache line:
+// the tail of k_tally_bits).  The price is a second dependent evaluation on the critical path.
+// The verdict words mean the same to k_resolve_band: slots before the published one are false.  A forced cursor
+// candidate (band cap exhausted) is evaluated first, on its own.
+// ---------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ int tree_eval(const int e, const bool forced, const int ce, const int mlo, const int mhi, const int (&thr)[NW],
+                                         int* pk, const int* __restrict__ L, const int* __restrict__ sp, const int* __restrict__ op,
+                                         const uint32_t* __restrict__ Mb32, const uint32_t tot2, const int npad, const int lane, u64& nfar_acc) {
+    using Gm = BitsGeom<NW>;
+    constexpr int W32 = 2 * NW, G = 64 / W32, PLT = ilog2_c(64 * NW) + 1;
+    const int ope = op[e], spe = sp[e];
+    int P[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) P[j] = L[(size_t)e * npad + j * 64 + lane];
+    if ((spe > ope ? spe : ope) >= mhi && !forced) return 2;   // FAR: a parent beyond the band
+    u64 farm[NW];
+    u64 nfar = 0;
+    uint32_t nvalid = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (a second evaluation of this wave reuses its hop list)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        int v = P[j];
+        if (j * 64 + lane == ce) v = spe;  // the row BEFORE the self overwrite (Q4)
+        P[j] = v;
+        const bool valid = v >= thr[j];
+        const bool inband = valid && v < mhi;
+        pk[Gm::slot(j * 64 + lane)] = inband ? v - mlo + 1 : 0;  // row 0 of the table is all-zero
+        farm[j] = __ballot(valid && !inband);
+        nfar += __popcll(farm[j]);
+        nvalid += __popcll(__ballot(valid));
+    }
+    if (3u * nvalid <= tot2) return 0;   // fewer valid hops than any column needs
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int w = lane % W32, g = lane / W32;
+    uint32_t b[PLT];
+    bits_accumulate_z<NW>(pk, Mb32, b, lane);
+    if (nfar) {  // rare: hops outside the band, masks built from their rows on the fly
+        nfar_acc += nfar;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            u64 far = farm[j];
+            while (far) {
+                const int h = __ffsll((long long)far) - 1;
+                far &= far - 1;
+                const int kf = __shfl(P[j], h);
+                uint32_t x = 0;
+#pragma unroll
+                for (int jj = 0; jj < NW; ++jj) {
+                    const int v = L[(size_t)kf * npad + jj * 64 + lane];
+                    const u64 bal = __ballot(v >= thr[jj]);
+                    if ((w >> 1) == jj) x = (uint32_t)(bal >> (32 * (w & 1)));
+                }
+                if (g == ((j * 64 + h) % G)) ripple_add<PLT>(b, x, 0);
+            }
+        }
+    }
+    const uint32_t gt = bits_finish_z<NW>(b, tot2 / 3u);
+    uint32_t cnt = (g == 0) ? __popc(gt) : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    return 3u * cnt > tot2 ? 1 : 0;   // count of members vs the STAKE threshold (Q2)
+}
+
+template <int NW>
+__global__ void __launch_bounds__(512)
+k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
+             const int* __restrict__ L, const int* __restrict__ sp, const int* __restrict__ op,
+             const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
+    using Gm = BitsGeom<NW>;
+    __shared__ __attribute__((aligned(16))) int s_pk[8][Gm::PK_INTS];
+    __shared__ int s_k1[8], s_k2[8];
+    __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
+    pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.unres); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand);
+    pin_arg(B.found64); pin_arg(B.gallop); pin_arg(B.treecnt); pin_arg(par); pin_arg(K); pin_arg(skip); pin_arg(mb_prefetch);
+    pin_arg(L); pin_arg(sp); pin_arg(op); pin_arg(Mb32); pin_arg(tot2); pin_arg(npad);
+    RState* st = B.st + (1 - par);  // written by k_resolve_band of this iteration
+    const size_t pb = (size_t)(1 - par) * npad;
+    const int lane = lane_id();
+    const int wib = threadIdx.x >> 6;
+    const int cm = blockIdx.x;
+    const int s_done = st->done, mlo = st->mlo, mhi = st->mhi;
+    int pf_dummy = 0;
+    if (mb_prefetch) {   // the first 64 waves of every XCD touch the band-mask table (written by the other XCDs), see k_tally_bits
+        const int wx = ((int)blockIdx.x >> 3) * 8 + wib;
+        const int nlines = ((mhi - mlo + 1) * NW * 8 + 127) >> 7;
+        const int line = wx * 64 + lane;
+        if (wx < 64 && line < nlines) {
+            const char* q = reinterpret_cast<const char*>(Mb32) + (size_t)line * 128;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(q) : "memory");
+        }
+    }
+    const int un = B.unres[pb + cm], frc = B.force[pb + cm], gsv = B.gallop[pb + cm];
+    const int ce_lane = B.cand[((size_t)(1 - par) * npad + cm) * 64 + lane];   // entry 1 + j = the event of slot j
+    int thr[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
+    const bool stamp = B.dbg && lane == 0 && wib == 0 && (cm == 0 || cm == (int)gridDim.x - 1);
+    const int sb = cm == 0 ? 16 : 24;
+    const int it_ = stamp ? st->iter - 1 : 0;
+    if (stamp && !s_done && it_ < SW_DBG_MAX_ITERS) B.dbg[(size_t)it_ * 32 + sb] = wall_clock64();
+    SW_STAMP(stamp && !s_done, it_, sb + 1);
+    if (s_done || !un) return;   // (uniform over the workgroup: nobody reaches a barrier)
+    const int live = __popcll(__ballot(lane >= 1 && lane <= K && ce_lane >= 0));   // candidates are contiguous from slot 0
+    if (live == 0) return;
+    auto slot_ev = [&](int j) -> int { return __shfl(ce_lane, j + 1); };
+    int* pk = s_pk[wib];
+    u64 nfar = 0;
+    int evals = 0;
+    int p = -1, kind = 0;   // the verdict: slot and what it is (1 PASS, 2 FAR); 0: every candidate of the window is false
+    if (frc) {   // rare: the cursor candidate is far and the band cannot grow — it is tallied with on-the-fly masks
+        int k0 = 0;
+        if (wib == 0) k0 = tree_eval<NW>(slot_ev(0), true, cm, mlo, mhi, thr, pk, L, sp, op, Mb32, tot2, npad, lane, nfar);
+        if (threadIdx.x == 0) s_k2[0] = k0;
+        __syncthreads();
+        if (s_k2[0] == 1) { p = 0; kind = 1; }
+        evals += 1;
+        __syncthreads();
+    }
+    SW_STAMP(stamp, it_, sb + 2);
+    if (kind == 0) {
+        const int s = (K + 7) >> 3;
+        const int nprobe = (live + s - 1) / s;   // <= 8
+        int k1 = 0;
+        // (a forced cursor candidate that failed above is known: evaluating slot 0 again, unforced, would call it FAR)
+        if (wib < nprobe) {
+            const int j1 = (wib + 1) * s - 1 < live - 1 ? (wib + 1) * s - 1 : live - 1;
+            if (!(frc && j1 == 0)) k1 = tree_eval<NW>(slot_ev(j1), false, cm, mlo, mhi, thr, pk, L, sp, op, Mb32, tot2, npad, lane, nfar);
+        }
+        if (lane == 0) s_k1[wib] = k1;
+        __syncthreads();
+        SW_STAMP(stamp, it_, sb + 3);
+        int qw = -1;
+#pragma unroll
+        for (int w2 = 7; w2 >= 0; --w2) if (w2 < nprobe && s_k1[w2] != 0) qw = w2;
+        evals += nprobe;
+        if (qw >= 0) {
+            const int prev = qw * s - 1;
+            const int q = (qw + 1) * s - 1 < live - 1 ? (qw + 1) * s - 1 : live - 1;
+            const int cnt2 = q - prev - 1;        // <= s - 1 <= 7 slots in between
+            int k2 = 0;
+            if (wib < cnt2 && !(frc && prev + 1 + wib == 0))
+                k2 = tree_eval<NW>(slot_ev(prev + 1 + wib), false, cm, mlo, mhi, thr, pk, L, sp, op, Mb32, tot2, npad, lane, nfar);
+            if (lane == 0) s_k2[wib] = k2;
+            __syncthreads();
+            p = q; kind = s_k1[qw];
+#pragma unroll
+            for (int i = 7; i >= 0; --i) if (i < cnt2 && s_k2[i] != 0) { p = prev + 1 + i; kind = s_k2[i]; }
+            evals += cnt2;
+        }
+    }
+    SW_STAMP(stamp, it_, sb + 4);
+    // (wave shuffles outside the one-thread branch: p is uniform over the workgroup)
+    const int pe = p >= 0 ? p : 0;
+    const int e = slot_ev(pe);
+    const bool use_la = NW <= 4 || K >= 32;   // (the table is published 63 positions far only then, see k_resolve_band)
+    const int la_i = pe + skip + K;
+    const int la_v = slot_ev(la_i < 64 ? la_i - 1 : 0);
+    const int la = (use_la && la_i < 64) ? la_v : -1;
+    if (threadIdx.x == 0) {
+        if (kind == 1) {
+            const int dl = ((gsv & 0xff) == 1 && la >= 0 && la - e < 0x3ffffff) ? la - e : 0x3ffffff;
+            B.found64[pb + cm] = ((u64)(uint32_t)e << 32) | ((u64)p << 26) | (u64)dl;
+        } else if (kind == 2) {
+            B.farslot[pb + cm] = p;
+        }
+        B.treecnt[cm] += evals;
+    }
+    if (lane == 0 && nfar) atomicAdd(&st->far_hops, nfar);
     asm volatile("" ::"v"(pf_dummy));   // (the touch's destination register stays reserved to the end)
     SW_STAMP(stamp, it_, sb + 5);
 }
@@ -2618,10 +2845,18 @@ k_order_firstdesc(const int* __restrict__ L, const int* __restrict__ cr, const i
                   const int* __restrict__ ordlo, const int* __restrict__ ordhi, int y0, int y1, int x0, int first_resident,
                   int ytile, int* FD) {
     constexpr int npad = 64 * NW;
-    constexpr int CG = npad / 8;          // columns per group
+    constexpr int CG = 8;                 // columns per workgroup: 32 bytes of a row
+    constexpr int NG = npad / CG;         // column groups
+    constexpr int GPX = NG / 8;           // ... per XCD (= NW)
     constexpr int YB = 256 / CG;          // events per pass of a workgroup
-    const int xg = blockIdx.x & 7, tile = blockIdx.x >> 3;
-    const int c = xg * CG + (int)(threadIdx.x % CG);
+    // Workgroup b runs on XCD b % 8 (observed; locality only).  The groups that share a 128-byte line of a row
+    // (4 groups = 32 columns) sit on ONE XCD, and consecutive workgroups of an XCD sweep its groups before they
+    // move to the next tile of events: the events in flight at any time span a few thousand indices, so the FD
+    // rows being filled (those of the last ~13 n events) stay in the XCD's L2 until their lines are complete.
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int sub = j % GPX, tile = j / GPX;
+    const int grp = GPX >= 4 ? (sub >> 2) * 32 + xcd * 4 + (sub & 3) : xcd * GPX + sub;
+    const int c = grp * CG + (int)(threadIdx.x % CG);
     const int yl = (int)(threadIdx.x / CG);
     const int plo = ordlo[c], phi = ordhi[c];   // chain positions of c ordered by this call: [plo, phi)
     if (phi <= plo) return;
@@ -2646,9 +2881,12 @@ k_order_firstdesc(const int* __restrict__ L, const int* __restrict__ cr, const i
         upper = upper < phi - 1 ? upper : phi - 1;
         if (upper < lower) continue;
         const int m = cr[y];
+        // what the consumer wants of y: its self-parent a (the sample is t[a]; "w sees x" is a < w on one chain), or,
+        // for a root, y itself (every later event of its creator sees it): stored as -2 - y
+        const int val = s >= 0 ? s : -2 - y;
         for (int p = lower; p <= upper; ++p) {
             const int x = chain_ev[cs + p];
-            FD[(size_t)(x - x0) * npad + m] = y;
+            FD[(size_t)(x - x0) * npad + m] = val;
         }
     }
 }
@@ -2657,7 +2895,7 @@ template <int MAXS>
 __global__ void __launch_bounds__(256)
 k_order_times_fd(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, int n_acc,
                  const int* __restrict__ fw_ev, const int* __restrict__ fw_cr, const int* __restrict__ fw_off,
-                 const int* __restrict__ FD, int x0, const int* __restrict__ sp, const double* __restrict__ t, int npad,
+                 const int* __restrict__ FD, int x0, const double* __restrict__ t, int npad,
                  double* ts, int* err) {
     __shared__ double s_t[4][MAXS];
     const int lane = lane_id();
@@ -2676,11 +2914,11 @@ k_order_times_fd(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri,
         double sample = 0.0;
         if (i < f1) {
             const int w = fw_ev[i];
-            const int y = row[fw_cr[i]];
-            if (y >= 0 && y <= w) {   // the first event of w's creator that sees x is w or a self-ancestor of w: w sees x (swirld.py:291-292)
+            const int v = row[fw_cr[i]];   // -1: no event of w's creator sees x; -2 - y: its root y does; else the self-parent of the first one that does
+            // the first event of w's creator that sees x is w or a self-ancestor of w  <=>  w sees x (swirld.py:291-292)
+            if (v <= -2 || (v >= 0 && v < w)) {
                 sees = true;
-                const int a = sp[y];
-                sample = t[a >= 0 ? a : y];   // its self-parent: the first self-ancestor that does NOT see x; a root stands for itself (Q11)
+                sample = t[v >= 0 ? v : -2 - v];   // the first self-ancestor that does NOT see x; a root stands for itself (Q11)
             }
         }
         const u64 bal = __ballot(sees);
@@ -2710,6 +2948,22 @@ k_order_times_fd(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri,
     const int l1 = __ffsll((long long)b1) - 1, l2 = __ffsll((long long)b2) - 1;
     const double r1 = __shfl(v1, l1), r2 = __shfl(v2, l2);
     if (lane == 0) ts[idx] = .5 * (r1 + r2);
+}
+
+// The events a call newly orders, round by round (swirld.py:288-293 as chain segments): segment (round entry i,
+// member m) = chain positions [start, q[i][m]) of m, written at offset `off` of the round-major list.  The host
+// computes start / off from the q table (one pass over entries x members); the events themselves never visit it.
+__global__ void k_order_segments(const int* __restrict__ q, const int* __restrict__ seg_start, const int* __restrict__ seg_off,
+                                 const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int npad, int total,
+                                 int* acc_ev, int* acc_ri) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int st = seg_start[i];
+    if (st < 0) return;
+    const int m = i % npad, ri = i / npad;
+    const int len = q[i] - st, off = seg_off[i];
+    const int* src = chain_ev + chain_start[m] + st;
+    for (int k = 0; k < len; ++k) { acc_ev[off + k] = src[k]; acc_ri[off + k] = ri; }
 }
 
 // whitening key of a decided round (swirld.py:285): XOR of its famous witnesses' signatures

@@ -159,6 +159,7 @@ struct sw_ctx {
     int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
     struct { int32_t* p = nullptr; } d_front;   // inside d_rb
+    int32_t* d_treecnt = nullptr;                // inside d_rb: tallies evaluated per member in the running loop (k_tally_tree)
     DBuf<unsigned char> d_small;   // device copy of the packed records of the current small append
     hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr;
     std::vector<int32_t> divided_cnt;   // per member: events already divided (chain positions below `divided`)
@@ -196,6 +197,7 @@ struct sw_ctx {
     int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int band_blocks = 512; // workgroups of the resolve+band kernel
+    int band_pre = 0;      // SW_BAND_PRE: events beyond the previous band whose rows the prefetch wave of k_resolve_band touches (0 = no prefetch wave)
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
     // round-loop graph
@@ -218,6 +220,7 @@ struct sw_ctx {
     std::vector<unsigned char> sig_h;        // host copy of the signatures (whitening, sort key)
     std::vector<int32_t> chain_start_h, chain_ev_h;
     DBuf<int32_t> d_fw_ev, d_fw_off, d_q, d_acc_ev, d_acc_ri, d_sorted, d_hostflag;
+    DBuf<int32_t> d_seg;   // find_order: [start | offset] of the newly ordered chain segments per (round entry, member)
     DBuf<int32_t> d_fw_cr, d_fd, d_ordhi;   // bulk find_order: creators of the famous witnesses, first-descendant table, end of the ordered chain segments
     DBuf<long long> d_acc_off;
     DBuf<unsigned char> d_white;
@@ -757,6 +760,7 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.cand = c->d_cand.p;
     B.gallop = c->d_gallop.p;
     B.front = c->d_front.p;
+    B.treecnt = c->d_treecnt;
     B.dbg = c->d_dbg;
     return B;
 }
@@ -774,14 +778,18 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
     const LoopBufs B = loop_bufs(c);
     Span sr{};
     if (resolve_spans) sr = span_begin(c);
-    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
+    const int pf = (bt + 64 <= 1024) ? c->band_pre : 0;   // band-row prefetch: one extra wave per workgroup
+    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt + (pf > 0 ? 64 : 0)), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW);
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, pf, (int)c->N);
     if (resolve_spans) { span_end(c, sr); resolve_spans->push_back(sr); }
     Span s{};
     if (tally_spans) s = span_begin(c);
-    if (c->unit_stake && c->tally_impl == 1)
+    if (c->unit_stake && c->tally_impl == 2)
+        hipLaunchKernelGGL(k_tally_tree<NW>, dim3(np), dim3(512), 0, c->stream, B, par, K, c->skip, c->tally_pf,
+                           (const int*)c->d_L.p, (const int*)c->d_sp.p, (const int*)c->d_op.p, (const uint32_t*)c->d_Mb.p, tot2, np);
+    else if (c->unit_stake && c->tally_impl >= 1)
         hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, c->tally_pf,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
@@ -816,7 +824,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     memset(&key, 0, sizeof key);
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
-    key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP;
+    key.BATCH = c->band_blocks + 4096 * c->skip + 65536 * (c->band_pre & 0x3fff); key.MCAP = c->MCAP + 7 * c->NEARCAP;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
         for (int g = 0; g < 3; ++g) {
             if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
@@ -895,6 +903,10 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         HIPCHK(c, hipMemcpyAsync(c->d_evalpos.p, c->d_evalpos.p + np, np * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     }
     c->R = st.max_round + 1;
+    if (c->unit_stake && c->tally_impl == 2) {   // the tree search counts the tallies it really evaluated (per member, read back with the state)
+        const int32_t* tc = reinterpret_cast<const int32_t*>(c->h_rb + ((unsigned char*)c->d_treecnt - c->d_rb));
+        for (int m = 0; m < np; ++m) c->ctr.tally_evals += tc[m];
+    } else
     c->ctr.tally_evals += (int64_t)st.evals;
     c->ctr.far_hops += (int64_t)st.far_hops;
     c->ctr.round_iterations += st.iter;
@@ -935,7 +947,7 @@ int launch_voter_masks(sw_ctx* c, int r0, int R, hipStream_t strm) {
     if (R <= r0) return SW_OK;
     const uint32_t tot2 = 2u * c->tot;
     const int total = (R - r0) * np;
-    if (c->unit_stake && c->tally_impl == 1)
+    if (c->unit_stake && c->tally_impl >= 1)
         hipLaunchKernelGGL(k_voter_masks_bits<NW>, dim3((total + 3) / 4), dim3(256), 0, strm,
                            (const int*)c->d_wit.p, (const int*)c->d_L.p, (const int*)c->d_lo.p, (const uint32_t*)c->d_S.p,
                            tot2, r0, R, np, (uint32_t*)c->d_Sw.p, c->d_fc);
@@ -1494,23 +1506,26 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     HIPCHK(c, hipMemcpyAsync(q.data(), c->d_q.p, q.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     lap("bounds");
-    // newly ordered chain segments per round (tbd = everything at or after ord_pos)
+    // newly ordered chain segments per round (tbd = everything at or after ord_pos): the host walks the q table
+    // (entries x members), the events are gathered on the device (k_order_segments)
     std::vector<int32_t> ord = c->ord_pos;
-    std::vector<int32_t> acc_ev, acc_ri;
     std::vector<int64_t> acc_off(nr + 1, 0);
+    std::vector<int32_t> seg((size_t)2 * nr * np, -1);   // [start | offset] per (entry, member); start -1: empty
+    int64_t n_acc = 0;
     for (int i = 0; i < nr; ++i) {
         for (int m = 0; m < n; ++m) {
             const int hi = q[(size_t)i * np + m];
             if (hi > ord[m]) {
-                const int32_t* seg = c->chain_ev_h.data() + (size_t)c->chain_start_h[m];
-                acc_ev.insert(acc_ev.end(), seg + ord[m], seg + hi);
+                seg[(size_t)i * np + m] = ord[m];
+                seg[(size_t)nr * np + (size_t)i * np + m] = (int32_t)n_acc;
+                n_acc += hi - ord[m];
                 ord[m] = hi;
             }
         }
-        acc_off[i + 1] = (int64_t)acc_ev.size();
-        acc_ri.resize(acc_ev.size(), i);
+        acc_off[i + 1] = n_acc;
     }
-    const int64_t n_acc = (int64_t)acc_ev.size();
+    if (n_acc > 0x7ffffff0ll) return fail(c, SW_ERANGE, "find_order: more than 2^31 events in one call");
+    std::vector<int32_t> acc_ev;   // host copy: fetched only for the rounds the host has to sort
     lap("segments");
     std::vector<double> ts((size_t)n_acc);
     std::vector<int32_t> sorted((size_t)n_acc), hostflag(nr, 0);
@@ -1518,8 +1533,12 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         CHK(dgrow(c, c->d_acc_ev, n_acc, 0));
         CHK(dgrow(c, c->d_acc_ri, n_acc, 0));
         CHK(dgrow(c, c->d_ts, n_acc, 0));
-        HIPCHK(c, hipMemcpyAsync(c->d_acc_ev.p, acc_ev.data(), n_acc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_acc_ri.p, acc_ri.data(), n_acc * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        CHK(dgrow(c, c->d_seg, seg.size(), 0));
+        HIPCHK(c, hipMemcpyAsync(c->d_seg.p, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_order_segments, dim3((unsigned)(((size_t)nr * np + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_q.p,
+                           (const int*)c->d_seg.p, (const int*)c->d_seg.p + (size_t)nr * np, (const int*)c->d_chain_start.p,
+                           (const int*)c->d_chain_ev.p, np, nr * np, c->d_acc_ev.p, c->d_acc_ri.p);
+        c->ctr.kernel_launches++;
         HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         CHK(dgrow(c, c->d_ordpos, np, 0));
         {
@@ -1552,22 +1571,24 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
             std::copy(ord.begin(), ord.end(), oh.begin());
             HIPCHK(c, hipMemcpyAsync(c->d_fw_cr.p, fw_cr.data(), fw_cr.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->d_ordhi.p, oh.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            lap("uploads");
             HIPCHK(c, hipMemsetAsync(c->d_fd.p, 0xff, (size_t)(x1 - x0) * np * sizeof(int32_t), c->stream));
-            const int ytile = 256;
+            lap("fd alloc+clear");
+            const int ytile = 64;    // (two passes of 32 events per workgroup: the events in flight stay within a few thousand indices)
             const int64_t tiles = (y1 - x0 + ytile - 1) / ytile;
             if (tiles > 0)
-                hipLaunchKernelGGL(k_order_firstdesc<NW>, dim3((unsigned)(tiles * 8)), dim3(256), 0, c->stream, (const int*)c->d_L.p,
+                hipLaunchKernelGGL(k_order_firstdesc<NW>, dim3((unsigned)(tiles * 8 * NW)), dim3(256), 0, c->stream, (const int*)c->d_L.p,
                                    (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
                                    (const int*)c->d_chain_ev.p, (const int*)c->d_ordpos.p, (const int*)c->d_ordhi.p, (int)x0, (int)y1, (int)x0,
                                    (int)c->first_resident, ytile, c->d_fd.p);
+            lap("firstdesc");
             hipLaunchKernelGGL(k_order_times_fd<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
                                (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
                                (const int*)c->d_fw_cr.p, (const int*)c->d_fw_off.p, (const int*)c->d_fd.p, (int)x0,
-                               (const int*)c->d_sp.p, (const double*)c->d_t.p, np, c->d_ts.p, c->d_err);
+                               (const double*)c->d_t.p, np, c->d_ts.p, c->d_err);
             c->ctr.kernel_launches += 2;
             HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging vectors above are locals)
-            // the table is as large as the can_see rows of the ordered range: given back when it is big
-            if (c->d_fd.cap * sizeof(int32_t) > ((size_t)256 << 20)) dfree(c->d_fd);
+            lap("times_fd");
         } else {
         hipLaunchKernelGGL(k_order_times<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
                            (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
@@ -1590,6 +1611,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
                            (const long long*)c->d_acc_off.p, (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p,
                            (const unsigned char*)c->d_white.p, c->d_sorted.p, c->d_hostflag.p);
         c->ctr.kernel_launches += 2;
+        lap("sort kernels");
         int err = 0;
         HIPCHK(c, hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(sorted.data(), c->d_sorted.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1601,7 +1623,9 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         if (getenv("SW_ORDER_HOST")) std::fill(hostflag.begin(), hostflag.end(), 1);  // test hook: host sort
         for (int i = 0; i < nr; ++i) any_flag = any_flag || hostflag[i];
         if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts and the signatures
+            acc_ev.resize((size_t)n_acc);
             HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_ts.p, n_acc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(acc_ev.data(), c->d_acc_ev.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             CHK(ensure_sig_h(c));
         }
@@ -1662,7 +1686,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
 // ====================================================================================
 extern "C" {
 
-int sw_version(void) { return 3; }
+int sw_version(void) { return 4; }
 
 const char* sw_last_error(const sw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1738,11 +1762,12 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->use_graph = graph != 0;
     knob("SW_BAND_BLOCKS", 1, 4096, &c->band_blocks);
     knob("SW_TALLY_PF", 0, 1, &c->tally_pf);
+    knob("SW_BAND_PRE", 0, 1 << 20, &c->band_pre);
     knob("SW_PIPE", 1, 64, &c->pipe);
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
     knob("SW_CANSEE_IMPL", 2, 6, &c->cansee_impl);
     if (c->cansee_impl == 4 || c->cansee_impl == 5) knob_err = "SW_CANSEE_IMPL: 6 (dataflow sweep), 2 or 3 (level-bucketed sweep)";
-    knob("SW_TALLY_IMPL", 0, 1, &c->tally_impl);
+    knob("SW_TALLY_IMPL", 0, 2, &c->tally_impl);   // 0 column-lane, 1 bit-sliced (one wave per slot), 2 bit-sliced two-level search (one workgroup per member)
     knob("SW_FLOW_CFG", 0, 3, &c->flow_cfg);
     knob("SW_CHUNKS", 1, SW_MAX_CHUNKS, &c->chunks);
     knob("SW_CHUNK_CFG", 0, 2, &c->chunk_cfg);
@@ -1810,7 +1835,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     }
     {
         static_assert(2 * sizeof(RState) + sizeof(int) <= 256, "readback block header");
-        const size_t prov_off = 256 + (size_t)c->npad * sizeof(int32_t);
+        const size_t tree_off = 256 + (size_t)c->npad * sizeof(int32_t);
+        const size_t prov_off = tree_off + (size_t)c->npad * sizeof(int32_t);
         c->rb_bytes = prov_off + (size_t)SW_PROV_ROWS * (SW_MAX_CHUNKS + 1) * sizeof(unsigned);
         CHIP(hipMalloc((void**)&c->d_rb, c->rb_bytes));
         CHIP(hipMemset(c->d_rb, 0, c->rb_bytes));
@@ -1818,6 +1844,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         c->d_state = reinterpret_cast<RState*>(c->d_rb);
         c->d_flow_err = reinterpret_cast<int*>(c->d_rb + 2 * sizeof(RState));
         c->d_front.p = reinterpret_cast<int32_t*>(c->d_rb + 256);
+        c->d_treecnt = reinterpret_cast<int32_t*>(c->d_rb + tree_off);
         c->d_prov = reinterpret_cast<unsigned*>(c->d_rb + prov_off);
     }
     CHIP(hipMalloc((void**)&c->d_err, sizeof(int)));
@@ -1901,7 +1928,7 @@ int sw_destroy(sw_ctx* c) {
     if (c->d_err) (void)hipFree(c->d_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
     dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_acc_off); dfree(c->d_white);
-    dfree(c->d_fw_cr); dfree(c->d_fd); dfree(c->d_ordhi);
+    dfree(c->d_fw_cr); dfree(c->d_fd); dfree(c->d_ordhi); dfree(c->d_seg);
     dfree(c->d_rbnd); dfree(c->d_rcuts);
     if (c->d_rprov) (void)hipFree(c->d_rprov);
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
@@ -3145,6 +3172,12 @@ int sw_get_transactions(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
 int sw_get_counters(sw_ctx* c, sw_counters* out) {
     if (!c || !out) return SW_EINVAL;
     *out = c->ctr;
+    return SW_OK;
+}
+
+int sw_get_counters_sized(sw_ctx* c, void* out, size_t out_bytes) {
+    if (!c || !out) return SW_EINVAL;
+    memcpy(out, &c->ctr, std::min(out_bytes, sizeof(sw_counters)));
     return SW_OK;
 }
 

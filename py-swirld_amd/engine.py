@@ -214,7 +214,8 @@ class Hashgraph:
     # ---- measurement ----
     def counters(self):
         c = Counters()
-        self._chk(self._L.sw_get_counters(self._h, C.byref(c)))
+        # (size-aware call: a library whose struct has grown cannot overrun this mirror)
+        self._chk(self._L.sw_get_counters_sized(self._h, C.byref(c), C.sizeof(c)))
         return {k: int(getattr(c, k)) for k, _ in Counters._fields_}
 
     def set_profiling(self, enable=True):

@@ -26,6 +26,7 @@ from time import time
 import numpy as np
 
 from . import crypto
+from ._lib import SwirldHipError
 from .engine import Hashgraph
 from .hgutils import bfs, randrange, toposort
 
@@ -154,13 +155,23 @@ class _VoterVotes(Mapping):
             raise KeyError(h)
         return int(nd._rounds()[e]), nd._mindex[nd.hg[h].c]
 
+    def _vote(self, rv, mv, rc, mc):
+        # SW_ENOTSUP from sw_get_vote (exact path; fame committed from a partitioned decide_fame, whose deciding
+        # voters are not recorded): "unknown", not "no such entry" 
+        try:
+            return self._n._dev.vote(rv, mv, rc, mc)
+        except SwirldHipError as exc:
+            if exc.code == -95:
+                raise VotesUnavailable(str(exc)) from None
+            raise
+
     def __getitem__(self, x):
         nd = self._n
         (rv, mv), (rc, mc) = self._slot(self._y), self._slot(x)
         wit = nd._witness_table()
         if wit[rv, mv] != nd._index[self._y] or wit[rc, mc] != nd._index[x]:
             raise KeyError(x)
-        v = nd._dev.vote(rv, mv, rc, mc)
+        v = self._vote(rv, mv, rc, mc)
         if v < 0:
             raise KeyError(x)
         return bool(v)
@@ -171,7 +182,7 @@ class _VoterVotes(Mapping):
         wit = nd._witness_table()
         for rc in range(rv):
             for mc in np.argsort(np.where(wit[rc] >= 0, wit[rc], np.iinfo(np.int32).max), kind="stable"):
-                if wit[rc, mc] >= 0 and nd._dev.vote(rv, mv, rc, int(mc)) >= 0:
+                if wit[rc, mc] >= 0 and self._vote(rv, mv, rc, int(mc)) >= 0:
                     yield nd._ids[wit[rc, mc]]
 
     def __len__(self):

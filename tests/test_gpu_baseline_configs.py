@@ -116,6 +116,26 @@ def test_coin_round_stress_bit_exact(pkg, oracle_pool, name):
     oracle_pool.drop(name)
 
 
+@pytest.mark.heavy("n1024_coin_200k")
+def test_1024_members_coin_rounds_bit_exact(pkg, oracle_pool):
+    """Coin rounds (swirld.py:267-272) at the width of configs[4], against the ORACLE: 1024 members, 40 % of them
+    nearly silent, 200 k events — every vote counter, the fame table and the rounds must be the reference
+    algorithm's (the wide elections kernel with coin rounds was oracle-checked up to 700 members before)."""
+    run = oracle_pool.get("n1024_coin_200k", timeout=2400)
+    o = run.oracle
+    co = o.counters()
+    if run.N >= 100_000:
+        assert co["coin_votes"] > 10_000 and co["max_vote_distance"] >= 6, "the case must reach coin rounds"
+    h, ncs = hip_run(pkg, run)
+    assert ncs == run.new_c
+    compare_state(h, o, run.N, can_see_rows=[(0, 4096), (run.N // 2, 2048), (run.N - 4096, 4096)])
+    c = h.counters()
+    for k in ("voter_evals", "majority_evals", "coin_votes", "coin_flips"):
+        assert c[k] == co[k], k
+    h.close()
+    oracle_pool.drop("n1024_coin_200k")
+
+
 def test_1024_members_coin_stress_properties(pkg):
     """1024 members with 40 % of them nearly silent (the shape of configs[4]; the oracle needs hours at
     this width): invariants of swirld.py:195-222, a prefix re-run, and coin rounds actually reached."""

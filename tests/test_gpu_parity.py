@@ -254,7 +254,7 @@ def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
 
 
 @pytest.mark.parametrize("cansee,tally,ring_h", [("2", "1", None), ("2", "1", "1"), ("2", "0", "4"), ("3", "1", "2"), ("3", "0", None),
-                                                 ("6", "1", None), ("6", "0", None)])
+                                                 ("6", "1", None), ("6", "0", None), ("6", "2", None), ("3", "2", None)])
 def test_kernel_variants_agree(pkg, monkeypatch, cansee, tally, ring_h):
     """Both can_see sweeps (level-bucketed with its LDS ring at several depths / dataflow) and both
     tally kernels (column-lane / bit-sliced) against the oracle, on inputs that stress the

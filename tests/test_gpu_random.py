@@ -22,7 +22,7 @@ def test_random_shapes(pkg, monkeypatch, seed):
     if rng.random() < 0.5:
         monkeypatch.setenv("SW_BAND_MAX", str(int(rng.choice([64, 1024, 1 << 20]))))
     monkeypatch.setenv("SW_CANSEE_IMPL", str(int(rng.choice([2, 3, 3, 6, 6, 6]))))
-    monkeypatch.setenv("SW_TALLY_IMPL", str(int(rng.choice([0, 1, 1]))))
+    monkeypatch.setenv("SW_TALLY_IMPL", str(int(rng.choice([0, 1, 1, 2, 2]))))
     monkeypatch.setenv("SW_SKIP", str(int(rng.choice([0, 1, 2, 2, 3, 7]))))
     if rng.random() < 0.25:
         monkeypatch.setenv("SW_GALLOP", str(int(rng.choice([1, 2, 3]))))
