@@ -1015,8 +1015,7 @@ __global__ void __launch_bounds__(1024)
 k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
-               const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb,
-               int pf_pre, int n_rows) {
+               const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb) {
     __shared__ int s_red[2][4][16];  // [parity][quantity][wave]: per-wave partial results
     __shared__ int s_thr[1024];
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
@@ -1029,43 +1028,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
     pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
-    pin_arg(pf_pre); pin_arg(n_rows);
-    // BAND-ROW PREFETCH (pf_pre > 0: the launch has one extra wave per workgroup).  The band phase below is one burst of
-    // row reads behind ~4 us of resolve step; the band of this iteration is, to 70-80 %, the previous one shifted by one
-    // round.  So while the member threads resolve, the extra wave touches the rows its workgroup's band waves will most
-    // likely read — the previous band plus `pf_pre` events, dealt to waves by ABSOLUTE groups of 8 events (group g belongs
-    // to band wave g mod nwaves, whatever the band) — one 128-byte line per lane, nothing waited for: the rows are in
-    // this XCD's L2 when the band waves ask for them.  The wave ends before the first barrier (ended waves are not counted).
-    const int nthr = (int)blockDim.x - (pf_pre > 0 ? 64 : 0);   // member / band threads of this workgroup
-    if (pf_pre > 0 && (int)threadIdx.x >= nthr) {
-        const RState* sp_ = B.st + par;
-        const int p_done = sp_->done, p_mlo = sp_->mlo, p_mhi = sp_->mhi, p_iter = sp_->iter;
-        const int skipw_ = gridDim.x > 1 ? 1 : 0;
-        if (p_done || p_iter == 0 || (skipw_ && blockIdx.x == 0)) return;
-        const int wpb_ = nthr >> 6;
-        const int nwaves_ = ((int)gridDim.x - skipw_) * wpb_;
-        const int lane_ = (int)threadIdx.x & 63;
-        int hi_ = p_mhi + pf_pre;
-        hi_ = hi_ < n_rows ? hi_ : n_rows;
-        const int g_lo = p_mlo >> 3;
-        int dummy = 0;
-        for (int wv = 0; wv < wpb_; ++wv) {
-            const int wave_ = ((int)blockIdx.x - skipw_) * wpb_ + wv;
-            int g = g_lo + ((wave_ - g_lo) % nwaves_ + nwaves_) % nwaves_;   // first group >= g_lo of this band wave
-            for (int rep = 0; rep < 2; ++rep, g += nwaves_) {
-                const int k = g * 8 + (lane_ >> 3);          // 8 rows of 8 lines (npad = 256) ...
-                if (k < hi_) {
-                    // ... in general: a row is npad * 4 / 128 lines; lane l takes line (l & 7) + 8 i of row l >> 3
-                    for (int ln = lane_ & 7; ln < npad / 32; ln += 8) {
-                        const char* q = reinterpret_cast<const char*>(L) + ((size_t)k * npad * 4 + (size_t)ln * 128);
-                        asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(q) : "memory");
-                    }
-                }
-            }
-        }
-        asm volatile("" ::"v"(dummy));
-        return;
-    }
+    const int nthr = (int)blockDim.x;
+    // (measured and dropped in round 4, profiles/r04d_*: an extra wave per workgroup that touches the rows of the previous
+    // band + one round while the member threads resolve.  The stamped block's band phase went from 3.4 to 2.1 us and the
+    // pass did not move: the band phase is bound by the bytes of the whole band, not by the latency of a wave's loads.)
     const RState* si = B.st + par;
     RState* so = B.st + (1 - par);
     const bool writer = blockIdx.x == 0;
@@ -1412,8 +1378,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     int t_[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) t_[j] = s_thr[j * 64 + lane];
-    // a wave takes the groups of 8 consecutive events g = wave (mod nwaves), by ABSOLUTE event index (what the
-    // prefetch wave assumed), the rows of up to RIF events in flight at once
+    // a wave takes the groups of 8 consecutive events g = wave (mod nwaves), by ABSOLUTE event index, the rows of up to
+    // RIF events in flight at once.  Measured and dropped in round 4 (profiles/r04e_*, r04f_*): the rows as ONE vector load
+    // per lane (dwordx4: 8.10 against 7.63 ms per pass), and a 16-bit side table of the rows relative to the event index
+    // (half the bytes: 8.34 ms with ushort loads, 8.77 ms with vector loads) — four dword loads per row it stays.
     const int g_first = mask_from >> 3;
     for (int g = g_first + ((wave - g_first) % nwaves + nwaves) % nwaves; g * 8 < mhi; g += nwaves) {
         // (masks are built for every band event: testing "can it be a hop at all" first would
@@ -2891,12 +2859,48 @@ k_order_firstdesc(const int* __restrict__ L, const int* __restrict__ cr, const i
     }
 }
 
+// Bitonic sort of 64 * E doubles held E per lane (element index = lane * E + r), ascending: the order statistics of a
+// wave's samples without the O(len^2) rank counting (21 cross-lane stages of E exchanges at E = 4 against ~560 LDS sweeps).
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(double (&v)[E], const int lane) {
+    constexpr int NTOT = 64 * E;
+#pragma unroll
+    for (int k = 2; k <= NTOT; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                const int lj = j / E;                       // partner lane = lane ^ lj, same register
+                const bool lower = (lane & lj) == 0;        // this lane holds the smaller index of the pair
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const bool up = ((lane * E + r) & k) == 0;
+                    const double o = __shfl_xor(v[r], lj);
+                    const double mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
+                    v[r] = (lower == up) ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & j) == 0) {
+                        const bool up = ((lane * E + r) & k) == 0;
+                        const double a = v[r], b2 = v[r | j];
+                        const bool sw = (a > b2) == up;
+                        v[r] = sw ? b2 : a;
+                        v[r | j] = sw ? a : b2;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int MAXS>
 __global__ void __launch_bounds__(256)
 k_order_times_fd(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, int n_acc,
                  const int* __restrict__ fw_ev, const int* __restrict__ fw_cr, const int* __restrict__ fw_off,
                  const int* __restrict__ FD, int x0, const double* __restrict__ t, int npad,
                  double* ts, int* err) {
+    constexpr int E = MAXS / 64;
     __shared__ double s_t[4][MAXS];
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
@@ -2927,27 +2931,24 @@ k_order_times_fd(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri,
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // order statistics len/2 and (len+1)/2 of the sorted samples (:304-305)
     const int k1 = len / 2, k2 = (len + 1) / 2;
     if (k2 >= len) {  // IndexError in the reference (len == 1, only with unequal stakes)
         if (lane == 0) { atomicExch(err, 1); ts[idx] = 0.0; }
         return;
     }
-    double v1 = 0.0, v2 = 0.0;
-    bool h1 = false, h2 = false;
-    for (int i = lane; i < len; i += 64) {
-        const double ti = st[i];
-        int rank = 0;
-        for (int j = 0; j < len; ++j) {
-            const double tj = st[j];
-            rank += (tj < ti) || (tj == ti && j < i);
-        }
-        if (rank == k1) { v1 = ti; h1 = true; }
-        if (rank == k2) { v2 = ti; h2 = true; }
-    }
-    const u64 b1 = __ballot(h1), b2 = __ballot(h2);
-    const int l1 = __ffsll((long long)b1) - 1, l2 = __ffsll((long long)b2) - 1;
-    const double r1 = __shfl(v1, l1), r2 = __shfl(v2, l2);
-    if (lane == 0) ts[idx] = .5 * (r1 + r2);
+    double v[E];
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+#pragma unroll
+    for (int r = 0; r < E; ++r) v[r] = lane * E + r < len ? st[lane * E + r] : inf;
+    wave_bitonic_sort<E>(v, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < E; ++r) st[lane * E + r] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) ts[idx] = .5 * (st[k1] + st[k2]);
 }
 
 // The events a call newly orders, round by round (swirld.py:288-293 as chain segments): segment (round entry i,

@@ -54,6 +54,7 @@ struct sw_ctx {
     int n = 0, nw = 0, npad = 0, coin_period = 6, device = 0;
     VmTable vm;
     int64_t first_resident = 0;   // can_see rows below this event index have been evicted (windowed mode)
+    bool vm_scratch_ok = false;   // windowed mode: the halo scratch rows behind row `cap` are mapped (the sweep may run in chunks)
     DBuf<int32_t> d_ordpos;       // per member: chain positions already ordered (find_order's search bound)
     // exact path for forked hashgraphs (exact.hip.h): entered at the first forked event, left by sw_reset
     bool exact = false;
@@ -197,7 +198,6 @@ struct sw_ctx {
     int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
     int band_blocks = 512; // workgroups of the resolve+band kernel
-    int band_pre = 0;      // SW_BAND_PRE: events beyond the previous band whose rows the prefetch wave of k_resolve_band touches (0 = no prefetch wave)
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
     // round-loop graph
@@ -392,6 +392,22 @@ size_t table_elems(const sw_ctx* c, int64_t cap) {
     return (size_t)(cap + (c->npad <= 256 ? SW_MAX_CHUNKS * c->halo : 0)) * c->npad;
 }
 
+// Windowed table: the halo scratch rows of the chunk-parallel sweep live behind row `cap` of the SAME address range
+// (one base pointer, as in the plain table): the chunks that hold rows [cap, cap + SW_MAX_CHUNKS * halo) are mapped
+// by the first call that is large enough to sweep in chunks (evictions work from the bottom and never reach them; when
+// the capacity grows the old scratch chunks simply become table rows and the new ones are mapped on demand).
+int vm_map_scratch(sw_ctx* c) {
+    VmTable& v = c->vm;
+    c->vm_scratch_ok = false;
+    if (!v.active || c->npad > 256) return SW_OK;
+    const size_t rowbytes = (size_t)c->npad * sizeof(int32_t);
+    const size_t a = (size_t)c->cap * rowbytes, b = ((size_t)c->cap + (size_t)c->chunks * (size_t)c->halo) * rowbytes;   // (chunk k uses block k)
+    if (b > v.va_bytes) return SW_OK;   // (no room in the reservation: the sweep stays unchunked)
+    for (size_t s_ = a / v.chunk; s_ <= (b - 1) / v.chunk; ++s_) CHK(vm_map_slot(c, s_));
+    c->vm_scratch_ok = true;
+    return SW_OK;
+}
+
 int ensure_events(sw_ctx* c, int64_t need) {
     if (need <= c->cap) return SW_OK;
     int64_t nc = c->cap ? c->cap : 0;
@@ -412,6 +428,7 @@ int ensure_events(sw_ctx* c, int64_t need) {
     // sweep's halos (k_cansee_chunks), SW_MAX_CHUNKS x halo rows
     if (!c->vm.active) CHK(dgrow(c, c->d_L, table_elems(c, nc), keep * c->npad));
     c->cap = nc;
+    c->vm_scratch_ok = false;   // (windowed table: the scratch rows sit behind row `cap`: mapped again on demand)
     return SW_OK;
 }
 
@@ -778,11 +795,10 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
     const LoopBufs B = loop_bufs(c);
     Span sr{};
     if (resolve_spans) sr = span_begin(c);
-    const int pf = (bt + 64 <= 1024) ? c->band_pre : 0;   // band-row prefetch: one extra wave per workgroup
-    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt + (pf > 0 ? 64 : 0)), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
+    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, pf, (int)c->N);
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW);
     if (resolve_spans) { span_end(c, sr); resolve_spans->push_back(sr); }
     Span s{};
     if (tally_spans) s = span_begin(c);
@@ -824,7 +840,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     memset(&key, 0, sizeof key);
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
-    key.BATCH = c->band_blocks + 4096 * c->skip + 65536 * (c->band_pre & 0x3fff); key.MCAP = c->MCAP + 7 * c->NEARCAP;
+    key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
         for (int g = 0; g < 3; ++g) {
             if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
@@ -1091,8 +1107,13 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     // ---- chunk plan: a sub-batch long enough is cut into G chunks that are swept concurrently, each from
     // `halo` events before its start (k_cansee_chunks); their chain positions come from one more search kernel
     c->chunk_plan.assign(S, sw_ctx::ChunkPlan{});
-    if (flow && !preswept && np <= 256 && c->chunks > 1 && !c->chunks_off && !c->vm.active && S <= SW_PROV_ROWS &&
-        c->d_L.cap >= table_elems(c, c->cap)) {   // (the halo scratch rows exist: they live behind the table's last row)
+    bool may_chunk = flow && !preswept && np <= 256 && c->chunks > 1 && !c->chunks_off && S <= SW_PROV_ROWS;
+    if (may_chunk && c->vm.active && !c->vm_scratch_ok) {   // windowed table: the scratch rows are mapped by the first call that can use them
+        bool any = false;
+        for (int i = 0; i < S; ++i) any = any || (cut[i + 1] - cut[i]) / c->chunk_min >= 2;
+        if (any) CHK(vm_map_scratch(c));
+    }
+    if (may_chunk && (c->vm.active ? c->vm_scratch_ok : c->d_L.cap >= table_elems(c, c->cap))) {   // (the halo scratch rows exist: they live behind the table's last row)
         std::vector<long long>& ccuts = c->ccuts_stage;
         ccuts.clear();
         int max_g = 0;
@@ -1512,7 +1533,9 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     std::vector<int64_t> acc_off(nr + 1, 0);
     std::vector<int32_t> seg((size_t)2 * nr * np, -1);   // [start | offset] per (entry, member); start -1: empty
     int64_t n_acc = 0;
+    std::vector<int32_t> ord_at((size_t)(nr + 1) * n);   // chain positions ordered before round entry i
     for (int i = 0; i < nr; ++i) {
+        std::copy(ord.begin(), ord.end(), ord_at.begin() + (size_t)i * n);
         for (int m = 0; m < n; ++m) {
             const int hi = q[(size_t)i * np + m];
             if (hi > ord[m]) {
@@ -1524,11 +1547,15 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         }
         acc_off[i + 1] = n_acc;
     }
+    std::copy(ord.begin(), ord.end(), ord_at.begin() + (size_t)nr * n);
     if (n_acc > 0x7ffffff0ll) return fail(c, SW_ERANGE, "find_order: more than 2^31 events in one call");
     std::vector<int32_t> acc_ev;   // host copy: fetched only for the rounds the host has to sort
     lap("segments");
-    std::vector<double> ts((size_t)n_acc);
-    std::vector<int32_t> sorted((size_t)n_acc), hostflag(nr, 0);
+    std::vector<double> ts;                                   // (host copy of the timestamps: only for rounds the host sorts)
+    std::vector<int32_t> hostflag(nr, 0);
+    const size_t tx_at = c->transactions.size();
+    c->transactions.resize(tx_at + (size_t)n_acc);              // the device-sorted order lands in place
+    int32_t* sorted = c->transactions.data() + tx_at;
     if (n_acc) {
         CHK(dgrow(c, c->d_acc_ev, n_acc, 0));
         CHK(dgrow(c, c->d_acc_ri, n_acc, 0));
@@ -1551,44 +1578,73 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         // search per (event, famous witness) pair.  Same samples, by construction and by test (SW_ORDER_BULK=<events>
         // moves the threshold, 0 = never).
         const int64_t bulk_min = getenv("SW_ORDER_BULK") ? atoll(getenv("SW_ORDER_BULK")) : 16384;   // (read per call: the tests force either path)
-        int64_t x0 = c->N, x1 = 0;
-        for (int m = 0; m < n; ++m)
-            if (ord[m] > c->ord_pos[m]) {
-                x0 = std::min<int64_t>(x0, c->chain_ev_h[(size_t)c->chain_start_h[m] + c->ord_pos[m]]);
-                x1 = std::max<int64_t>(x1, (int64_t)c->chain_ev_h[(size_t)c->chain_start_h[m] + ord[m] - 1] + 1);
-            }
-        // (a table beyond SW_ORDER_TMAX_MB [16384] is not built: the searches serve such a call)
-        const int64_t tmax = (getenv("SW_ORDER_TMAX_MB") ? atoll(getenv("SW_ORDER_TMAX_MB")) : 16384) << 20;
-        const bool bulk = bulk_min > 0 && n_acc >= bulk_min && (x1 - x0) * (int64_t)np * 4 <= tmax;
+        const bool bulk = bulk_min > 0 && n_acc >= bulk_min;
         if (bulk) {
-            int64_t y1 = 0;
+            // The table is built for GROUPS of consecutive round entries whose events span at most SW_ORDER_SLAB_MB [128] of
+            // FD rows: a slab that stays allocated (and mostly cache-resident) instead of one table as large as the
+            // can_see rows of everything the call orders.
+            const int64_t slab_rows = std::max<int64_t>(4096, ((getenv("SW_ORDER_SLAB_MB") ? atoll(getenv("SW_ORDER_SLAB_MB")) : 128) << 20) / ((int64_t)np * 4));
             std::vector<int32_t> fw_cr(fw_ev.size());
-            for (size_t i = 0; i < fw_ev.size(); ++i) { fw_cr[i] = c->cr[fw_ev[i]]; y1 = std::max<int64_t>(y1, (int64_t)fw_ev[i] + 1); }
+            for (size_t i = 0; i < fw_ev.size(); ++i) fw_cr[i] = c->cr[fw_ev[i]];
             CHK(dgrow(c, c->d_fw_cr, std::max<size_t>(fw_cr.size(), 1), 0));
-            CHK(dgrow(c, c->d_fd, (size_t)(x1 - x0) * np, 0));
-            CHK(dgrow(c, c->d_ordhi, np, 0));
-            std::vector<int32_t> oh(np, 0);
-            std::copy(ord.begin(), ord.end(), oh.begin());
             HIPCHK(c, hipMemcpyAsync(c->d_fw_cr.p, fw_cr.data(), fw_cr.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->d_ordhi.p, oh.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            struct Group { int i0, i1; int64_t x0, x1, y1; };
+            std::vector<Group> groups;
+            auto span_of = [&](int i0, int i1, int64_t* x0, int64_t* x1) {   // events ordered by the entries [i0, i1)
+                *x0 = c->N; *x1 = 0;
+                const int32_t *lo_ = ord_at.data() + (size_t)i0 * n, *hi_ = ord_at.data() + (size_t)i1 * n;
+                for (int m = 0; m < n; ++m)
+                    if (hi_[m] > lo_[m]) {
+                        const int32_t* ch = c->chain_ev_h.data() + (size_t)c->chain_start_h[m];
+                        *x0 = std::min<int64_t>(*x0, ch[lo_[m]]);
+                        *x1 = std::max<int64_t>(*x1, (int64_t)ch[hi_[m] - 1] + 1);
+                    }
+            };
+            for (int i0 = 0; i0 < nr;) {
+                int i1 = i0 + 1;
+                int64_t x0, x1;
+                span_of(i0, i1, &x0, &x1);
+                while (i1 < nr) {   // grow the group while its span fits the slab
+                    int64_t nx0, nx1;
+                    span_of(i0, i1 + 1, &nx0, &nx1);
+                    if (nx1 - nx0 > slab_rows) break;
+                    x0 = nx0; x1 = nx1; ++i1;
+                }
+                int64_t y1 = 0;
+                for (int j = fw_off[i0]; j < fw_off[i1]; ++j) y1 = std::max<int64_t>(y1, (int64_t)fw_ev[j] + 1);
+                if (acc_off[i1] > acc_off[i0]) groups.push_back({i0, i1, x0, x1, y1});
+                i0 = i1;
+            }
+            int64_t max_rows = 0;
+            for (const Group& g : groups) max_rows = std::max(max_rows, g.x1 - g.x0);
+            CHK(dgrow(c, c->d_fd, (size_t)max_rows * np, 0));
+            CHK(dgrow(c, c->d_ordhi, (size_t)2 * np * std::max<size_t>(groups.size(), 1), 0));
+            std::vector<int32_t> oh((size_t)2 * np * std::max<size_t>(groups.size(), 1), 0);
+            for (size_t gi = 0; gi < groups.size(); ++gi) {
+                std::copy(ord_at.begin() + (size_t)groups[gi].i0 * n, ord_at.begin() + (size_t)(groups[gi].i0 + 1) * n, oh.begin() + (size_t)2 * np * gi);
+                std::copy(ord_at.begin() + (size_t)groups[gi].i1 * n, ord_at.begin() + (size_t)(groups[gi].i1 + 1) * n, oh.begin() + (size_t)2 * np * gi + np);
+            }
+            HIPCHK(c, hipMemcpyAsync(c->d_ordhi.p, oh.data(), oh.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             lap("uploads");
-            HIPCHK(c, hipMemsetAsync(c->d_fd.p, 0xff, (size_t)(x1 - x0) * np * sizeof(int32_t), c->stream));
-            lap("fd alloc+clear");
-            const int ytile = 64;    // (two passes of 32 events per workgroup: the events in flight stay within a few thousand indices)
-            const int64_t tiles = (y1 - x0 + ytile - 1) / ytile;
-            if (tiles > 0)
-                hipLaunchKernelGGL(k_order_firstdesc<NW>, dim3((unsigned)(tiles * 8 * NW)), dim3(256), 0, c->stream, (const int*)c->d_L.p,
-                                   (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
-                                   (const int*)c->d_chain_ev.p, (const int*)c->d_ordpos.p, (const int*)c->d_ordhi.p, (int)x0, (int)y1, (int)x0,
-                                   (int)c->first_resident, ytile, c->d_fd.p);
-            lap("firstdesc");
-            hipLaunchKernelGGL(k_order_times_fd<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
-                               (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
-                               (const int*)c->d_fw_cr.p, (const int*)c->d_fw_off.p, (const int*)c->d_fd.p, (int)x0,
-                               (const double*)c->d_t.p, np, c->d_ts.p, c->d_err);
-            c->ctr.kernel_launches += 2;
+            for (size_t gi = 0; gi < groups.size(); ++gi) {
+                const Group& g = groups[gi];
+                HIPCHK(c, hipMemsetAsync(c->d_fd.p, 0xff, (size_t)(g.x1 - g.x0) * np * sizeof(int32_t), c->stream));
+                const int ytile = 64;    // (two passes of 32 events per workgroup: the events in flight stay within a few thousand indices)
+                const int64_t tiles = (g.y1 - g.x0 + ytile - 1) / ytile;
+                if (tiles > 0)
+                    hipLaunchKernelGGL(k_order_firstdesc<NW>, dim3((unsigned)(tiles * 8 * NW)), dim3(256), 0, c->stream, (const int*)c->d_L.p,
+                                       (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
+                                       (const int*)c->d_chain_ev.p, (const int*)c->d_ordhi.p + (size_t)2 * np * gi, (const int*)c->d_ordhi.p + (size_t)2 * np * gi + np,
+                                       (int)g.x0, (int)g.y1, (int)g.x0, (int)c->first_resident, ytile, c->d_fd.p);
+                const int64_t a0 = acc_off[g.i0], na = acc_off[g.i1] - acc_off[g.i0];
+                hipLaunchKernelGGL(k_order_times_fd<64 * NW>, dim3((unsigned)((na + 3) / 4)), dim3(256), 0, c->stream,
+                                   (const int*)c->d_acc_ev.p + a0, (const int*)c->d_acc_ri.p + a0, (int)na, (const int*)c->d_fw_ev.p,
+                                   (const int*)c->d_fw_cr.p, (const int*)c->d_fw_off.p, (const int*)c->d_fd.p, (int)g.x0,
+                                   (const double*)c->d_t.p, np, c->d_ts.p + a0, c->d_err);
+                c->ctr.kernel_launches += 2;
+            }
             HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging vectors above are locals)
-            lap("times_fd");
+            lap("firstdesc+times");
         } else {
         hipLaunchKernelGGL(k_order_times<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
                            (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
@@ -1614,16 +1670,20 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         lap("sort kernels");
         int err = 0;
         HIPCHK(c, hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(sorted.data(), c->d_sorted.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sorted, c->d_sorted.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hostflag.data(), c->d_hostflag.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
-        if (err) return fail(c, SW_ERANGE, "find_order: an event is seen by a single famous witness (IndexError at swirld.py:305)");
+        if (err) {
+            c->transactions.resize(tx_at);   // nothing of this call is kept
+            return fail(c, SW_ERANGE, "find_order: an event is seen by a single famous witness (IndexError at swirld.py:305)");
+        }
         bool any_flag = false;
         if (getenv("SW_ORDER_HOST")) std::fill(hostflag.begin(), hostflag.end(), 1);  // test hook: host sort
         for (int i = 0; i < nr; ++i) any_flag = any_flag || hostflag[i];
         if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts and the signatures
             acc_ev.resize((size_t)n_acc);
+            ts.resize((size_t)n_acc);
             HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_ts.p, n_acc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(acc_ev.data(), c->d_acc_ev.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1636,12 +1696,8 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     int64_t produced = 0;
     std::vector<Item> items;
     for (int i = 0; i < nr; ++i) {
-        if (!hostflag[i]) {  // sorted on the device
-            const int64_t cnt = acc_off[i + 1] - acc_off[i];
-            c->transactions.insert(c->transactions.end(), sorted.begin() + acc_off[i], sorted.begin() + acc_off[i + 1]);
-            if (out_events && produced < cap)
-                memcpy(out_events + produced, sorted.data() + acc_off[i], (size_t)std::min<int64_t>(cnt, cap - produced) * sizeof(int32_t));
-            produced += cnt;
+        if (!hostflag[i]) {  // sorted on the device: already in `transactions`
+            produced += acc_off[i + 1] - acc_off[i];
             continue;
         }
         unsigned char white[64] = {0};  // swirld.py:285
@@ -1665,12 +1721,9 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
             }
             return x.ev < y.ev;
         });
-        for (const Item& it : items) {  // swirld.py:307-309
-            c->transactions.push_back(it.ev);
-            if (out_events && produced < cap) out_events[produced] = it.ev;
-            ++produced;
-        }
+        for (const Item& it : items) sorted[produced++] = it.ev;   // swirld.py:307-309
     }
+    if (out_events && n_acc) memcpy(out_events, sorted, (size_t)std::min<int64_t>(n_acc, cap) * sizeof(int32_t));
     lap("sort");
     c->ord_pos.swap(ord);
     CHK(window_evict(c));
@@ -1762,7 +1815,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->use_graph = graph != 0;
     knob("SW_BAND_BLOCKS", 1, 4096, &c->band_blocks);
     knob("SW_TALLY_PF", 0, 1, &c->tally_pf);
-    knob("SW_BAND_PRE", 0, 1 << 20, &c->band_pre);
     knob("SW_PIPE", 1, 64, &c->pipe);
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
     knob("SW_CANSEE_IMPL", 2, 6, &c->cansee_impl);
@@ -2860,6 +2912,7 @@ int sw_rewind(sw_ctx* c) {
         CHK(vm_flush_translations(c));
         v.base = (char*)base;
         v.lo = 0; v.hi = 0;
+        c->vm_scratch_ok = false;
         c->d_L.p = (int32_t*)base;
         c->first_resident = 0;
         CHK(vm_ensure(c, (size_t)c->N * c->npad * sizeof(int32_t)));

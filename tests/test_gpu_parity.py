@@ -375,3 +375,4 @@ def test_full_size_properties(pkg):
     # determinism
     h3, ncs3 = hip_run(pkg, n, stream)
     assert ncs3 == ncs and np.array_equal(h3.rounds(), rnd) and np.array_equal(h3.famous(), fam)
+

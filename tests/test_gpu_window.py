@@ -46,7 +46,9 @@ def test_windowed_run_matches_oracle(pkg, n, N, chunk, mode, p0, p1):
     assert ei.value.code == -34 and h.num_events == N
     # a rewind recomputes everything from event 0: the evicted chunks are mapped again
     h.rewind()
+    sweeps0 = h.counters()["chunk_sweeps"]
     h.divide_rounds(0, N)
+    assert h.counters()["chunk_sweeps"] > sweeps0, "one large call under the windowed table sweeps in chunks (halo scratch rows mapped behind the table)"
     h.decide_fame()
     hr = h.rounds()
     if not np.array_equal(hr, o.round):   # say where the two part: the first wrong round and the wrong can_see rows
