@@ -107,114 +107,20 @@ def time_python_reference(ref_path, n, stream, events):
         return {"same_run": False, "error": repr(exc)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--members", type=int, default=256)
-    ap.add_argument("--events", type=int, default=1_000_000)
-    ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=300_000,
-                    help="events of the same stream timed through the CPU oracle (0 = skip)")
-    ap.add_argument("--contexts", type=int, default=4, help="max resident replicas of the DAG per GPU")
-    ap.add_argument("--mode", type=int, default=0, help="generator mode (0 uniform gossip = the benchmark; 1 cliques, 2 slow members, 3 stale other-parents: robustness runs)")
-    ap.add_argument("--p0", type=float, default=0.0)
-    ap.add_argument("--p1", type=float, default=0.0)
-    ap.add_argument("--e2e-steps", type=int, default=3, help="end-to-end passes (host arrays in, results on host); 0 = skip")
-    ap.add_argument("--split", choices=["replicas", "strong"], default="replicas",
-                    help="which multi-GPU number is `value`: independent replicas (default) or ONE hashgraph over the GPUs")
-    ap.add_argument("--emulate-parts", type=int, default=0,
-                    help="1 GPU only: also run the one-hashgraph split with this many contexts on the one device (no parallelism: "
-                         "a functional run that reports the per-range sweep time and the rows moved)")
-    ap.add_argument("--reference-path", default="/root/reference", help="source tree of the Python reference (timed in-run when present)")
-    ap.add_argument("--reference-events", type=int, default=8000, help="prefix of the stream timed through the Python reference (~20 s at 256 members)")
-    args = ap.parse_args()
-
-    import torch
-    rep_mod = importlib.import_module("py-swirld_amd.replicas")
-    rank, local_rank, world = rep_mod.dist_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    # N > 1: independent replicas, one per GPU; RCCL only for the barrier and the max-over-ranks time
-    rep = rep_mod.Replicas(backend="nccl", device=torch.device("cuda", local_rank))
-
-    pkg = importlib.import_module("py-swirld_amd")
-    n, N = args.members, args.events
-    stream = pkg.synth_hashgraph(n, N, rep_mod.replica_seed(args.seed, rank), args.mode, args.p0, args.p1)  # host, untimed
-    n_ctx = max(1, min(args.contexts, args.steps + args.warmup))
-    ctxs = []
-    t_ing0 = time.perf_counter()
-    for _ in range(n_ctx):
-        h = pkg.Hashgraph(n, device=local_rank)
-        h.reserve(N)
-        h.append_events(*stream)  # ingest (Node.add_event): outside the timed region of `value`
-        ctxs.append(h)
-    ingest_s = (time.perf_counter() - t_ing0) / n_ctx
-    for h in ctxs:  # set-up: every resident context builds its launch graphs once
-        h.divide_rounds(0, N)
-        h.decide_fame()
-
-    def one_step(i):
-        h = ctxs[i % n_ctx]
-        h.rewind()  # ALWAYS inside the timed bracket: every step starts from "events ingested, nothing divided"
-        h.divide_rounds(0, N)
-        return h.decide_fame()
-
-    def barrier():
-        rep.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        one_step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        new_c = one_step(i)
-    barrier()
-    dt = rep.max_over_ranks(time.perf_counter() - t0)
-    ms_per_step = dt / args.steps * 1e3
-    value = world * N * args.steps / dt
-
-    # ---- end to end: host SoA in -> round[N], witness table, famous, new_c on the host ----
-    e2e = None
-    if args.e2e_steps > 0:
-        h = ctxs[-1]
-
-        def e2e_step():
-            h.reset()                      # forget the events too (device storage stays allocated)
-            h.append_events(*stream)
-            h.divide_rounds(0, N)
-            nc = h.decide_fame()
-            return h.rounds(), h.witnesses(), h.famous(), nc
-
-        e2e_step()  # warm-up
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.e2e_steps):
-            r_e2e = e2e_step()
-        barrier()
-        dt_e2e = rep.max_over_ranks(time.perf_counter() - t1) / args.e2e_steps
-        e2e = {"events_per_s": round(world * N / dt_e2e, 1), "ms_per_pass": round(dt_e2e * 1e3, 3),
-               "includes": "sw_reset + sw_append_events (93 B/event over PCIe: parents, t, 64-byte signature) + "
-                           "sw_divide_rounds + sw_decide_fame + round[N] / witness table / famous read-back"}
-        assert len(r_e2e[0]) == N and list(r_e2e[3]) == list(new_c)
-
-    # ---- ONE hashgraph over the GPUs (north_star's split; SURVEY.md §8e): the same stream on every rank ----
+def strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, N, stream, new_c, barrier):
+    """The one-hashgraph split, timed (world > 1) or emulated with several contexts on one device (--emulate-parts)."""
     strong = None
-    part_mod = importlib.import_module("py-swirld_amd.partition")
     if world > 1 and npad_of(n) <= 256:
         import torch.distributed as dist
+
         dev = torch.device("cuda", local_rank)
         s_stream = pkg.synth_hashgraph(n, N, args.seed, args.mode, args.p0, args.p1)
         hs = pkg.Hashgraph(n, device=local_rank)
         hs.reserve(N)
         hs.append_events(*s_stream)
-        ss = part_mod.StrongSplit(dist, rank, world, device=dev)
-        back = part_mod.HipRangeBackend(hs, dev)
+        on_dev = args.backend == "nccl"   # RCCL moves device tensors; gloo (functional runs on one GPU) gets host-staged rows
+        ss = part_mod.StrongSplit(dist, rank, world, device=dev if on_dev else None)
+        back = part_mod.HipRangeBackend(hs, dev) if on_dev else part_mod.HostStagedRangeBackend(hs, dev)
 
         def strong_step():
             hs.rewind()
@@ -271,6 +177,147 @@ def main():
                           "range_sweep_ms_each is what one rank spends before its rows can travel"}
         for h_ in hp:
             h_.close()
+
+    return strong
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--members", type=int, default=256)
+    ap.add_argument("--events", type=int, default=1_000_000)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=300_000,
+                    help="events of the same stream timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--contexts", type=int, default=4, help="max resident replicas of the DAG per GPU")
+    ap.add_argument("--mode", type=int, default=0, help="generator mode (0 uniform gossip = the benchmark; 1 cliques, 2 slow members, 3 stale other-parents: robustness runs)")
+    ap.add_argument("--p0", type=float, default=0.0)
+    ap.add_argument("--p1", type=float, default=0.0)
+    ap.add_argument("--e2e-steps", type=int, default=3, help="end-to-end passes (host arrays in, results on host); 0 = skip")
+    ap.add_argument("--split", choices=["replicas", "strong"], default="replicas",
+                    help="which multi-GPU number is `value`: independent replicas (default) or ONE hashgraph over the GPUs")
+    ap.add_argument("--emulate-parts", type=int, default=0,
+                    help="1 GPU only: also run the one-hashgraph split with this many contexts on the one device (no parallelism: "
+                         "a functional run that reports the per-range sweep time and the rows moved)")
+    ap.add_argument("--concurrent", type=int, default=2, help="also time this many contexts dividing at once on the one GPU (0 / 1 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo with --one-device: a functional "
+                                                     "run of the multi-rank code on a box with one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="test hook: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--reference-path", default="/root/reference", help="source tree of the Python reference (timed in-run when present)")
+    ap.add_argument("--reference-events", type=int, default=8000, help="prefix of the stream timed through the Python reference (~20 s at 256 members)")
+    args = ap.parse_args()
+
+    import torch
+    rep_mod = importlib.import_module("py-swirld_amd.replicas")
+    rank, local_rank, world = rep_mod.dist_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.one_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    # N > 1: independent replicas, one per GPU; the collectives of `value` are the barrier and the max-over-ranks time
+    rep = rep_mod.Replicas(backend=args.backend, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+
+    pkg = importlib.import_module("py-swirld_amd")
+    n, N = args.members, args.events
+    stream = pkg.synth_hashgraph(n, N, rep_mod.replica_seed(args.seed, rank), args.mode, args.p0, args.p1)  # host, untimed
+    n_ctx = max(1, min(args.contexts, args.steps + args.warmup))
+    ctxs = []
+    t_ing0 = time.perf_counter()
+    for _ in range(n_ctx):
+        h = pkg.Hashgraph(n, device=local_rank)
+        h.reserve(N)
+        h.append_events(*stream)  # ingest (Node.add_event): outside the timed region of `value`
+        ctxs.append(h)
+    ingest_s = (time.perf_counter() - t_ing0) / n_ctx
+    for h in ctxs:  # set-up: every resident context builds its launch graphs once
+        h.divide_rounds(0, N)
+        h.decide_fame()
+
+    def one_step(i):
+        h = ctxs[i % n_ctx]
+        h.rewind()  # ALWAYS inside the timed bracket: every step starts from "events ingested, nothing divided"
+        h.divide_rounds(0, N)
+        return h.decide_fame()
+
+    def barrier():
+        rep.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        new_c = one_step(i)
+    barrier()
+    dt = rep.max_over_ranks(time.perf_counter() - t0)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * N * args.steps / dt
+
+    # ---- two passes at once on ONE GPU (two contexts, two host threads): how much of the chip one latency-bound pass leaves
+    # idle.  Reported next to `value`, never as `value`: a node divides ONE hashgraph, and ms_per_step is that pass's latency.
+    conc = None
+    if args.concurrent > 1 and n_ctx >= args.concurrent and world == 1:
+        import threading
+        per = max(2, args.steps // args.concurrent)
+
+        def worker(j):
+            hj = ctxs[j]
+            for _ in range(per):
+                hj.rewind()
+                hj.divide_rounds(0, N)
+                hj.decide_fame()
+
+        ths = [threading.Thread(target=worker, args=(j,)) for j in range(args.concurrent)]
+        torch.cuda.synchronize()
+        tcc = time.perf_counter()
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        torch.cuda.synchronize()
+        dcc = time.perf_counter() - tcc
+        conc = {"contexts": args.concurrent, "events_per_s": round(args.concurrent * per * N / dcc, 1), "passes_each": per,
+                "ms_per_pass_each": round(dcc / per * 1e3, 3),
+                "note": "independent hashgraph views dividing at the same time on one GPU (the C calls release the GIL); the metric's "
+                        "`value` is ONE pass at a time"}
+
+    # ---- end to end: host SoA in -> round[N], witness table, famous, new_c on the host ----
+    e2e = None
+    if args.e2e_steps > 0:
+        h = ctxs[-1]
+
+        def e2e_step():
+            h.reset()                      # forget the events too (device storage stays allocated)
+            h.append_events(*stream)
+            h.divide_rounds(0, N)
+            nc = h.decide_fame()
+            return h.rounds(), h.witnesses(), h.famous(), nc
+
+        e2e_step()  # warm-up
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.e2e_steps):
+            r_e2e = e2e_step()
+        barrier()
+        dt_e2e = rep.max_over_ranks(time.perf_counter() - t1) / args.e2e_steps
+        e2e = {"events_per_s": round(world * N / dt_e2e, 1), "ms_per_pass": round(dt_e2e * 1e3, 3),
+               "includes": "sw_reset + sw_append_events (93 B/event over PCIe: parents, t, 64-byte signature) + "
+                           "sw_divide_rounds + sw_decide_fame + round[N] / witness table / famous read-back"}
+        assert len(r_e2e[0]) == N and list(r_e2e[3]) == list(new_c)
+
+    # ---- ONE hashgraph over the GPUs (north_star's split; SURVEY.md §8e): the same stream on every rank ----
+    strong = None
+    part_mod = importlib.import_module("py-swirld_amd.partition")
+    try:
+        strong = strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, N, stream, new_c, barrier)
+    except Exception as exc:  # noqa: BLE001 — the replicas line is still printed; the failure is part of it
+        strong = {"error": repr(exc)}
 
     # ---- per-kernel roofline table: one extra profiled pass (plain launches, hipEvent pairs) ----
     h = ctxs[0]
@@ -413,6 +460,7 @@ def main():
             "value_end_to_end": e2e["events_per_s"] if e2e else None,
             "end_to_end": e2e,
             "value_replicas": round(value_replicas, 1), "ms_per_step_replicas": round(ms_replicas, 3),
+            "value_concurrent_contexts": conc,
             "value_strong": strong["events_per_s"] if strong and "events_per_s" in strong else None,
             "strong": strong,
             "value_with_order": round(N / ((ms_replicas + find_order_ms) * 1e-3), 1) if world == 1 else None,

@@ -262,6 +262,9 @@ int sw_get_timings(sw_ctx* ctx, sw_timings* out);
  * stamp their phases (100 MHz clock) per iteration; copies up to cap_words of the
  * [4096 iterations][32] table of the most recent run.  profiles/loop_phases.py reads it. */
 int sw_debug_clocks(sw_ctx* ctx, unsigned long long* out, int64_t cap_words);
+/* Diagnostics: with SW_DEBUG_CLOCKS=3 every workgroup of the two round-loop kernels stamps the time it was done: copies up
+ * to cap_words of the [4096 iterations][2 kernels][2048 workgroups] table.  profiles/block_ends.py reads it. */
+int sw_debug_block_clocks(sw_ctx* ctx, unsigned long long* out, int64_t cap_words);
 
 /* Measurement utility (no reference counterpart): forget all voting state (rounds,
  * witnesses, fame, consensus, order) as if divide_rounds had never been called; the

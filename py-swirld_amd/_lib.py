@@ -76,6 +76,7 @@ SIGNATURES = {
     "sw_set_profiling": (C.c_int, [_P, C.c_int]),
     "sw_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "sw_debug_clocks": (C.c_int, [_P, _P, C.c_int64]),
+    "sw_debug_block_clocks": (C.c_int, [_P, _P, C.c_int64]),
     "sw_set_forks": (C.c_int, [_P, C.c_int]),
     "sw_get_exact": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "sw_get_witness_order": (C.c_int, [_P, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),

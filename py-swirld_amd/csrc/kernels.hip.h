@@ -785,6 +785,8 @@ k_cansee_chunks(const int4* __restrict__ cdesc, const int* __restrict__ chain_st
         else if constexpr (H >= 16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if (!__ballot(p < pend)) break;
+        // (measured and dropped in round 4, profiles/r04g_*: starved waves sleeping 128 cycles per unproductive trip to leave the
+        // CU to the round-loop kernels: the pass gets 0.4 % slower, hot-member hashgraphs 3 %)
     }
     if (!exact && w_k > a0) {
         unsigned tot = n_prov;
@@ -963,6 +965,8 @@ struct LoopBufs {
     int* treecnt;     // [npad] tallies evaluated for the member in this run (k_tally_tree: one workgroup owns a member; read back with the loop state)
     int* front;       // [npad] per member the last round r with lo[r][member] finite (-1 none): where the next call resumes
     u64* dbg;         // diagnostics (SW_DEBUG_CLOCKS=1): [iteration][32] wall-clock stamps, else null
+    u64* dbg_blk;     // diagnostics (SW_DEBUG_CLOCKS=3): [iteration][2][2048] end time of every workgroup of the two loop kernels, else null
+    int dbg_minor;    // ... 1: every phase of the resolve step is stamped (each stamp drains the wave: SW_DEBUG_CLOCKS=2 keeps only entry / band start / end)
 };
 
 // Kernel arguments are fetched lazily by the compiler (an s_load right before the first use, one
@@ -1157,7 +1161,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // lies before that creator's cursor; otherwise c waits for the next iteration.  When both
     // parents have round <= r the candidate needs a real tally: the band cap is doubled.
     int grow = 0;
-    SW_STAMP(stamp, iter, sb + 2);
+    SW_STAMP(stamp && B.dbg_minor, iter, sb + 2);
     if (iter > 0) {
         if (member) {
             // a member is "resolved for round r" unless it is still searching
@@ -1185,6 +1189,9 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     const int rl = c & 63, rw = c >> 6, nwv = nthr >> 6;
     int nun = 0;
     {   // count(un) and any(grow) with one barrier
+        // (round 4, measured and dropped — profiles/r04i_*: the next round's entry counts computed speculatively and reduced on
+        // THIS barrier, and the inheritance pass skipped unless a tally flagged a FAR candidate: the resolve step went from
+        // 3.44 to 3.13 us, the band phase behind it from 2.28 to 2.59 us, the iteration stayed at 18.1 us)
         const u64 bu = __ballot(un != 0), bg = __ballot(grow != 0);
         if (rl == 0) { s_red[0][0][rw] = __popcll(bu); s_red[0][1][rw] = bg != 0; }
         __syncthreads();
@@ -1192,7 +1199,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         for (int w = 0; w < nwv; ++w) { nun += s_red[0][0][w]; anyg |= s_red[0][1][w]; }
         if (anyg && ncap < MCAP) ncap = ncap * 2 < MCAP ? ncap * 2 : MCAP;
     }
-    SW_STAMP(stamp, iter, sb + 3);
+    SW_STAMP(stamp && B.dbg_minor, iter, sb + 3);
     int need_mask = 0, done = 0, err = 0, max_round = 0;
     if (nun == 0) {
         int lr, nx, start;
@@ -1216,7 +1223,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             start = (member && r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
             nx = lo_r1;
         }
-        SW_STAMP(stamp, iter, 8);
+        SW_STAMP(stamp && B.dbg_minor, iter, 8);
         int lp = 1;  // s_red[0] was used by the count above
         for (;;) {  // enter the next round that has unresolved members
             if (r + 1 >= Rcap) { err = 1; done = 1; break; }
@@ -1247,10 +1254,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                 }
                 lp ^= 1;
             }
-            SW_STAMP(stamp, iter, 10);
+            SW_STAMP(stamp && B.dbg_minor, iter, 10);
             if (nact == 0) { done = 1; max_round = r - 1; break; }
             if (nun > 0) {
-                SW_STAMP(stamp, iter, 11);
+                SW_STAMP(stamp && B.dbg_minor, iter, 11);
                 mlo = minlr;
                 thr = lr;
                 my_lo_next = SW_INF;
@@ -1268,12 +1275,12 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         }
     }
     if (done) un = 0;
-    SW_STAMP(stamp, iter, sb + 4);
+    SW_STAMP(stamp && B.dbg_minor, iter, sb + 4);
     // candidates of member c in the next tally launch: chain positions [curc, curc + K)
     const int live = !un ? 0 : strd == 1 ? (clen - curc < K ? clen - curc : K)
                                          : ((clen - 1 - curc) / strd + 1 < K ? (clen - 1 - curc) / strd + 1 : K);
     const int maxc = !live ? -1 : (curc == spec_cur && strd == 1 ? spec_last : chain_ev[cs + curc + (live - 1) * strd]);
-    SW_STAMP(stamp, iter, 12);
+    SW_STAMP(stamp && B.dbg_minor, iter, 12);
     int s_max = -1, s_cnt = 0;
     {   // max(last candidate), sum(evaluated) and the thresholds for the band, one barrier
         // (the [.][3] slots are written only here, once per launch)
@@ -1294,7 +1301,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             s_cnt += s_red[1][3][w];
         }
     }
-    SW_STAMP(stamp, iter, 13);
+    SW_STAMP(stamp && B.dbg_minor, iter, 13);
     // Candidate table for the tally (saves it a dependent round trip): workgroup b publishes the
     // window of member b.  The load is issued here and the store deferred behind the band rows, so
     // that it costs this kernel no round trip of its own.
@@ -1319,6 +1326,11 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     }
     auto flush_cand = [&]() {
         if (cand_mine) B.cand[((size_t)(1 - par) * npad + blockIdx.x) * 64 + threadIdx.x] = cand_v;
+        if (B.dbg_blk && iter < SW_DBG_MAX_ITERS) {   // (diagnostics: when this workgroup was done)
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (threadIdx.x == 0 && blockIdx.x < 2048) B.dbg_blk[((size_t)iter * 2 + 0) * 2048 + blockIdx.x] = wall_clock64();
+        }
     };
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
     // (hops beyond the cap are rebuilt from their rows by the tally kernel)
@@ -1335,7 +1347,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             need_mask = 1;
         }
     }
-    SW_STAMP(stamp, iter, 14);
+    SW_STAMP(stamp && B.dbg_minor, iter, 14);
     if (writer) {
         if (member) {
             B.unres[out + c] = un;
@@ -1890,6 +1902,12 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     }
     asm volatile("" ::"v"(pf_dummy));   // (the touch's destination register stays reserved to the end)
     SW_STAMP(stamp, it_, sb + 5);
+    if (B.dbg_blk) {   // (diagnostics: when this workgroup was done)
+        const int itb = st->iter - 1;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && itb >= 0 && itb < SW_DBG_MAX_ITERS) B.dbg_blk[((size_t)itb * 2 + 1) * 2048 + blockIdx.x] = wall_clock64();
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -2077,6 +2095,12 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     asm volatile("" ::"v"(pf_dummy));   // (the touch's destination register stays reserved to the end)
     SW_STAMP(stamp, it_, sb + 5);
 }
+
+// (Round 4, measured and dropped — profiles/r04j_*, r04k_*: the workgroups of k_tally_bits finish in dispatch order over 5.7 us
+// although a wave lives 2 us on average, which reads like a launch-rate bound.  A kernel with a quarter of the waves — one
+// workgroup per member, every wave evaluating four slots at once with interleaved gathers — does start and end within 1.9 us,
+// but its waves then take 10 us: the same 58 MB of mask gathers go through L2 at the same ~13 TB/s, and the four counts are a
+// serial instruction stream nothing hides.  The tally is bound by the L2 gather rate; 7 waves per SIMD is how it is hidden.)
 
 // ---------------------------------------------------------------------------------
 // Finalize: round numbers (swirld.py:217-219) and sees-masks for the events of the batch.

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -159,10 +160,12 @@ struct sw_ctx {
     double stage_us[8] = {0};    // sw_divide_rounds host stages: sweeps enqueued, loop set-up, round loop, front rows, aux launches, final syncs
     int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
+    unsigned long long* d_dbg_blk = nullptr;   // SW_DEBUG_CLOCKS=3: end time of every workgroup of the loop kernels, per iteration
+    int dbg_minor = 1;                    // SW_DEBUG_CLOCKS=2: only the entry / band start / end stamps (the others drain the wave)
     struct { int32_t* p = nullptr; } d_front;   // inside d_rb
     int32_t* d_treecnt = nullptr;                // inside d_rb: tallies evaluated per member in the running loop (k_tally_tree)
     DBuf<unsigned char> d_small;   // device copy of the packed records of the current small append
-    hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr;
+    hipEvent_t ev_aux_done = nullptr, ev_cs_done = nullptr, ev_main_mark = nullptr, ev_bounds = nullptr, ev_loop_done = nullptr;
     std::vector<int32_t> divided_cnt;   // per member: events already divided (chain positions below `divided`)
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_farslot, d_force, d_cand, d_gallop;
@@ -779,6 +782,8 @@ LoopBufs loop_bufs(sw_ctx* c) {
     B.front = c->d_front.p;
     B.treecnt = c->d_treecnt;
     B.dbg = c->d_dbg;
+    B.dbg_minor = c->dbg_minor;
+    B.dbg_blk = c->d_dbg_blk;
     return B;
 }
 
@@ -868,7 +873,8 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
 }
 
 template <int NW>
-int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, const int32_t* visible_len, float* tally_ms_out, int* tally_launches_out) {
+int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, const int32_t* visible_len, float* tally_ms_out, int* tally_launches_out,
+                   const std::function<int()>* after_first_shot = nullptr) {
     const int np = c->npad, K = c->K;
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
                        (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p);
@@ -891,6 +897,9 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     for (;;) {
         CHK(ensure_rounds(c, c->R + launched + shot + 4));
         CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr, c->profiling ? &resolve_spans : nullptr));
+        // host work that is off the critical path (the finalize / witness / voter-mask launches of the PREVIOUS sub-batch, on
+        // their own stream) goes here: the GPU is already busy with this sub-batch's first shot
+        if (launched == 0 && after_first_shot) CHK((*after_first_shot)());
         launched += shot;
         HIPCHK(c, hipGetLastError());
         // loop state, sweep error flag (the sweep of this sub-batch is complete) and the members' front
@@ -1087,6 +1096,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     // ends at the last appended event (a Node's call) is known on the host: chain lengths at the last
     // divide and now.  Otherwise device binary searches over the chain pool.
     std::vector<int32_t>& bounds_h = c->bounds_stage;
+    bool bounds_pending = false;
     bounds_h.resize((size_t)(S + 1) * np);
     CHK(dgrow(c, c->d_bounds, (size_t)(S + 1) * np, 0));
     if (S == 1 && first + K == c->N) {
@@ -1101,8 +1111,12 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         hipLaunchKernelGGL(k_chain_bounds, dim3(S + 1), dim3(np), 0, cs, (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p,
                            (const int*)c->d_chain_ev.p, (const long long*)c->d_cuts.p, np, c->d_bounds.p);
         c->ctr.kernel_launches++;
+        // (read back behind the kernel; the host needs the table only for the round loops below: it waits for
+        // `ev_bounds` there, after every sweep has been enqueued — the GPU starts sweeping ~0.1 ms earlier)
         HIPCHK(c, hipMemcpyAsync(bounds_h.data(), c->d_bounds.p, bounds_h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipStreamSynchronize(cs));
+        if (!c->ev_bounds) HIPCHK(c, hipEventCreateWithFlags(&c->ev_bounds, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_bounds, cs));
+        bounds_pending = true;
     }
     // ---- chunk plan: a sub-batch long enough is cut into G chunks that are swept concurrently, each from
     // `halo` events before its start (k_cansee_chunks); their chain positions come from one more search kernel
@@ -1175,6 +1189,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     if (c->profiling) (void)hipEventRecord(cs_t1, cs);
     clk.mark(&c->stage_us[0]);
 
+    if (bounds_pending) HIPCHK(c, hipEventSynchronize(c->ev_bounds));
     // ---- round loops, one per sub-batch, each over the events visible so far
     CHK(ensure_rounds(c, std::max(c->R, 1) + c->BATCH + 4));
     Span sp_rl = span_begin(c);
@@ -1184,6 +1199,8 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     int r_min = 0x7fffffff;
     // members' visible chain lengths before this call and after every sub-batch: rows of the cut table
     std::vector<int32_t> clen_prev(bounds_h.begin(), bounds_h.begin() + np), clen(np, 0);
+    bool aux_armed = false;
+    std::function<int()> pending_aux = []() -> int { return SW_OK; };
     for (int i = 0; i < S; ++i) {
         const int64_t limit = cut[i + 1];
         int r_start = 0x7fffffff;
@@ -1213,7 +1230,8 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         const int64_t dbg_it0 = c->ctr.round_iterations;
         if (dbg_t) (void)hipStreamSynchronize(c->stream);  // separates "waiting for the sweep" from the loop itself
         const auto dbg_t1 = std::chrono::steady_clock::now();
-        CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], c->d_bounds.p + (size_t)(i + 1) * np, &tally_ms, &tally_launches));
+        CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], c->d_bounds.p + (size_t)(i + 1) * np, &tally_ms, &tally_launches, &pending_aux));
+        CHK(pending_aux());   // (a loop that returned before its first shot — never — would have left it undone)
         if (dbg_t) {
             const auto dbg_t2 = std::chrono::steady_clock::now();
             const double w = std::chrono::duration<double, std::milli>(dbg_t1 - dbg_t0).count();
@@ -1246,25 +1264,35 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         clk.mark(&c->stage_us[3]);
         // The rounds of every event below `limit` are final now (later sub-batches only add lo
         // entries that compare greater than every existing event), so their round numbers,
-        // sees-masks, witness rows and voter masks are produced right away on a third stream,
-        // overlapping the round loop of the next sub-batch.
+        // sees-masks, witness rows and voter masks are produced on a third stream, overlapping the
+        // round loop of the next sub-batch — and ENQUEUED behind that loop's first shot (they must wait for
+        // this loop's kernels, which the aux stream learns from an event recorded here).
         {
-            hipStream_t ax = c->stream_aux;
             CHK(ensure_rounds(c, R + 2));
             const int64_t a0 = cut[i], k0 = cut[i + 1] - cut[i];
-            if (i == 0 && c->profiling) { fin_t0 = next_event(c); (void)hipEventRecord(fin_t0, ax); }
-            const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, 8192);
-            hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, ax, (const int*)c->d_L.p,
-                               (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)a0, (int)k0, c->d_round.p, c->d_S.p, np);
-            const int total = (R - r_start) * np;
-            if (total > 0)
-                hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, ax,
-                                   (const int*)c->d_lo.p, R, r_start, np, c->d_wit.p);
-            c->ctr.kernel_launches += 2;
-            CHK(launch_voter_masks<NW>(c, r_start, R, ax));
+            const int rs_ = r_start, i_ = i;
+            HIPCHK(c, hipEventRecord(c->ev_loop_done, c->stream));
+            aux_armed = true;
+            pending_aux = [c, np, R, a0, k0, rs_, i_, &fin_t0, &aux_armed]() -> int {
+                if (!aux_armed) return SW_OK;
+                aux_armed = false;
+                hipStream_t ax = c->stream_aux;
+                HIPCHK(c, hipStreamWaitEvent(ax, c->ev_loop_done, 0));
+                if (i_ == 0 && c->profiling) { fin_t0 = next_event(c); (void)hipEventRecord(fin_t0, ax); }
+                const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, 8192);
+                hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, ax, (const int*)c->d_L.p,
+                                   (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)a0, (int)k0, c->d_round.p, c->d_S.p, np);
+                const int total = (R - rs_) * np;
+                if (total > 0)
+                    hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, ax,
+                                       (const int*)c->d_lo.p, R, rs_, np, c->d_wit.p);
+                c->ctr.kernel_launches += 2;
+                return launch_voter_masks<NW>(c, rs_, R, ax);
+            };
         }
         clk.mark(&c->stage_us[4]);
     }
+    CHK(pending_aux());   // the last sub-batch's
     span_end(c, sp_rl);
 
     const int R = c->R;
@@ -1840,6 +1868,11 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         else (void)hipMemset(c->d_flow_dbg, 0, 8 * sizeof(u64));
     }
     if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
+        c->dbg_minor = atoi(getenv("SW_DEBUG_CLOCKS")) >= 2 ? 0 : 1;
+        if (atoi(getenv("SW_DEBUG_CLOCKS")) == 3) {
+            if (hipMalloc(&c->d_dbg_blk, (size_t)SW_DBG_MAX_ITERS * 2 * 2048 * 8) != hipSuccess) c->d_dbg_blk = nullptr;
+            else (void)hipMemset(c->d_dbg_blk, 0, (size_t)SW_DBG_MAX_ITERS * 2 * 2048 * 8);
+        }
         if (hipMalloc(&c->d_dbg, (size_t)SW_DBG_MAX_ITERS * 32 * 8) != hipSuccess) c->d_dbg = nullptr;
         else (void)hipMemset(c->d_dbg, 0, (size_t)SW_DBG_MAX_ITERS * 32 * 8);
     }
@@ -1921,6 +1954,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     CHIP(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
     CHIP(hipEventCreateWithFlags(&c->ev_cs_done, hipEventDisableTiming));
     CHIP(hipEventCreateWithFlags(&c->ev_main_mark, hipEventDisableTiming));
+    CHIP(hipEventCreateWithFlags(&c->ev_loop_done, hipEventDisableTiming));
     CCHK(dgrow(c, c->d_chain_len, np, 0));
     CCHK(dgrow(c, c->d_chain_start, np, 0));
     CCHK(dgrow(c, c->d_chain_cnt, np, 0));
@@ -1973,6 +2007,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
+    if (c->d_dbg_blk) (void)hipFree(c->d_dbg_blk);
     dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_rsc); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
     if (c->d_rb) (void)hipFree(c->d_rb);
     if (c->h_rb) (void)hipHostFree(c->h_rb);
@@ -1995,6 +2030,8 @@ int sw_destroy(sw_ctx* c) {
     if (c->ev_aux_done) (void)hipEventDestroy(c->ev_aux_done);
     if (c->ev_cs_done) (void)hipEventDestroy(c->ev_cs_done);
     if (c->ev_main_mark) (void)hipEventDestroy(c->ev_main_mark);
+    if (c->ev_bounds) (void)hipEventDestroy(c->ev_bounds);
+    if (c->ev_loop_done) (void)hipEventDestroy(c->ev_loop_done);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->ev_small) (void)hipEventDestroy(c->ev_small);
@@ -3246,6 +3283,15 @@ int sw_debug_clocks(sw_ctx* c, unsigned long long* out, int64_t cap_words) {
     const int64_t nw = std::min<int64_t>(cap_words, (int64_t)SW_DBG_MAX_ITERS * 32);
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(out, c->d_dbg, (size_t)nw * 8, hipMemcpyDeviceToHost));
+    return SW_OK;
+}
+
+int sw_debug_block_clocks(sw_ctx* c, unsigned long long* out, int64_t cap_words) {
+    if (!c || !out) return SW_EINVAL;
+    if (!c->d_dbg_blk) return fail(c, SW_EINVAL, "sw_debug_block_clocks: the context was not created with SW_DEBUG_CLOCKS=3");
+    const int64_t nw = std::min<int64_t>(cap_words, (int64_t)SW_DBG_MAX_ITERS * 2 * 2048);
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->d_dbg_blk, (size_t)nw * 8, hipMemcpyDeviceToHost));
     return SW_OK;
 }
 

@@ -233,6 +233,12 @@ class Hashgraph:
         self._chk(self._L.sw_debug_clocks(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
 
+    def debug_block_clocks(self, iters=1024):
+        """[iters][2][2048] uint64: when every workgroup of k_resolve_band / the tally kernel was done (SW_DEBUG_CLOCKS=3)."""
+        out = np.zeros((int(iters), 2, 2048), np.uint64)
+        self._chk(self._L.sw_debug_block_clocks(self._h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
     def set_forks(self, accept=True):
         """Forked events: accepted (the context moves to the exact path, csrc/exact.hip.h — the reference's
         statements on the device, identical results, far slower) or refused with SW_ENOTSUP."""

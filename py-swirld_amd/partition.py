@@ -169,6 +169,34 @@ class HipRangeBackend:
         return self.h.commit_fame(fam, dec)
 
 
+class HostStagedRangeBackend(HipRangeBackend):
+    """The same C-ABI calls with the travelling rows staged through HOST tensors: for process groups that cannot move
+    device memory (gloo in the functional tests; `bench.py --backend gloo --one-device`).  RCCL moves device tensors
+    directly (HipRangeBackend)."""
+
+    def __init__(self, hashgraph, device):
+        super().__init__(hashgraph, device)
+        self._keep = []
+
+    def row_buffer(self, K):
+        return self.torch.empty(int(K) * self.h.row_stride, dtype=self.torch.int32)
+
+    def export_rows(self, a, K, buf):
+        tmp = self.torch.empty(buf.numel(), dtype=self.torch.int32, device=self.device)
+        self.h.export_rows(a, K, tmp.data_ptr(), self._stream())
+        buf.copy_(tmp)                  # (a synchronising copy on the current stream, which waits for the export)
+
+    def import_rows(self, a, K, buf):
+        tmp = buf.to(self.device)
+        self._keep.append(tmp)          # the import copies asynchronously: the staging tensor outlives the call
+        self.h.import_rows(a, K, tmp.data_ptr(), self._stream())
+
+    def divide_rounds(self, a, K):
+        super().divide_rounds(a, K)     # (host-blocking: every import enqueued before it has completed on return)
+        if a + K >= self.h.num_events:
+            self._keep.clear()
+
+
 class StrongSplit:
     """ONE hashgraph over the `world` ranks of a torch.distributed group (north_star: "events are partitioned
     across the GPUs ... allreduce of per-witness vote bitmasks").  Every rank holds the whole

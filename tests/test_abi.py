@@ -99,6 +99,13 @@ def test_committed_measurement_fixtures_bench_reads():
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         tr = json.load(f)
     assert tr["commit"] and tr["kernels"]["k_cansee_chunks"] > 0 and tr["kernels"]["k_tally_bits"] > 0
+    # the counter passes must have been taken on THIS tree's kernels: the file carries the SHA-256 of
+    # csrc/kernels.hip.h it was measured on; bench.py quotes nothing from a stale file, and this test says so loudly
+    import hashlib
+    with open(os.path.join(ROOT, "py-swirld_amd", "csrc", "kernels.hip.h"), "rb") as f:
+        now = hashlib.sha256(f.read()).hexdigest()
+    assert tr.get("kernels_sha256") == now, ("profiles/traffic.json was measured on other kernel source (commit %s): "
+                                             "run profiles/run_profiles.sh on the GPU box and copy its traffic.json" % tr["commit"])
     with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
         rp = json.load(f)
     assert rp["reference_equals_oracle_on_this_prefix"] is True and rp["members"] == 256 and rp["events_per_s"] > 0

@@ -133,32 +133,13 @@ except Exception as exc:
     on_device = False
 
 
-class HostStaged(part.HipRangeBackend):
-    # the same C-ABI calls; the broadcast tensors live on the host (what gloo moves in any build)
-    def __init__(self, h, dev):
-        super().__init__(h, dev)
-        self.keep = []
-    def row_buffer(self, K):
-        return torch.empty(int(K) * self.h.row_stride, dtype=torch.int32)
-    def export_rows(self, a, K, buf):
-        tmp = torch.empty(buf.numel(), dtype=torch.int32, device=self.device)
-        self.h.export_rows(a, K, tmp.data_ptr(), self._stream())
-        buf.copy_(tmp)                                  # (synchronising copy on the current stream, which waits for the export)
-    def import_rows(self, a, K, buf):
-        tmp = buf.to(self.device)
-        self.keep.append(tmp)                           # the import copies asynchronously: the staging tensor outlives the call
-        self.h.import_rows(a, K, tmp.data_ptr(), self._stream())
-    def divide_rounds(self, a, K):
-        super().divide_rounds(a, K)
-
-
 ok = True
 for n, N, seed, mode, p0, p1 in [(64, 50000, 631, 0, 0, 0), (40, 30000, 632, 2, 0.3, 0.02)]:
     stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
     h = pkg.Hashgraph(n)
     h.append_events(*stream)
     ss = part.StrongSplit(dist, rank, world, device=dev if on_device else None)
-    back = part.HipRangeBackend(h, dev) if on_device else HostStaged(h, dev)
+    back = part.HipRangeBackend(h, dev) if on_device else part.HostStagedRangeBackend(h, dev)
     for step in range(2):                                # twice: the staging buffers are reused
         h.rewind()
         ss.divide_rounds(back, N)
@@ -171,7 +152,7 @@ for n, N, seed, mode, p0, p1 in [(64, 50000, 631, 0, 0, 0), (40, 30000, 632, 2, 
     ok = ok and new_c == nco and np.array_equal(h.rounds(), o.round) and np.array_equal(h.can_see(), o.can_see) \
         and np.array_equal(h.famous()[m], o.famous_by_event[wit[m]]) and np.array_equal(h.consensus(), o.consensus())
     h.close()
-print("RANK %%d %%s" %% (rank, "OK" if ok else "MISMATCH"), flush=True)
+print("RANK %%d %%s (rows travelled as %%s tensors)" %% (rank, "OK" if ok else "MISMATCH", "device" if on_device else "host"), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
