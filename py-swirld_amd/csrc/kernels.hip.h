@@ -2048,6 +2048,9 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         const int nprobe = (live + s - 1) / s;   // <= 8
         int k1 = 0;
         // (a forced cursor candidate that failed above is known: evaluating slot 0 again, unforced, would call it FAR)
+        // (round 4, measured and dropped — profiles/r04m_*: the rows of a wave's bracket loaded with its probe's row and their hop
+        // lists staged in LDS before the barrier, so that level 2 starts at the gathers: level 2 went from 2.4 to 2.0 us, level 1
+        // from 2.4 to 3.7 us)
         if (wib < nprobe) {
             const int j1 = (wib + 1) * s - 1 < live - 1 ? (wib + 1) * s - 1 : live - 1;
             if (!(frc && j1 == 0)) k1 = tree_eval<NW>(slot_ev(j1), false, cm, mlo, mhi, thr, pk, L, sp, op, Mb32, tot2, npad, lane, nfar);

@@ -199,7 +199,10 @@ struct sw_ctx {
     int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers: k_cansee_chunks / k_cansee_flow); 2 / 3 = level-bucketed sweep (k_cansee_stream, 1024 / 256 threads: the default beyond 256 members)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
     int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
-    int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced (unit stake only)
+    int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced, one wave per slot (unit stake only), 2 = bit-sliced two-level search (k_tally_tree)
+    bool tally_auto = true;   // SW_TALLY_IMPL not set: large calls of ~256-member hashgraphs without strongly skewed activity use 2
+    bool K_auto = true;       // SW_TALLY_K not set: 28 slots for the flat tally, 32 for the tree
+    int K_flat = 28;
     int band_blocks = 512; // workgroups of the resolve+band kernel
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
@@ -1051,6 +1054,20 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     cut.push_back(first + K);
     const int S = (int)cut.size() - 1;
     const bool flow = c->cansee_impl >= 6;
+    // Which tally (round 4, profiles/r04l_*): the two-level search with a window of 32 wins on 256-member hashgraphs whose
+    // members are about equally active — uniform gossip +2.6 %, two cliques +18 %, stale other-parents +16 %, 4 M events
+    // +4.7 %, mild skew +5 % — and loses where a third of the members is 50 times less active (-9 %) and at 64 / 128
+    // members (-8 / -10 %).  Decided per large call from the members' event counts; SW_TALLY_IMPL / SW_TALLY_K pin it.
+    if (c->tally_auto && c->unit_stake) {
+        int impl = 1;
+        if (np == 256 && n > 200 && K >= 65536) {
+            int32_t lo_ = 0x7fffffff, hi_ = 0;
+            for (int m = 0; m < n; ++m) { lo_ = std::min(lo_, c->nev[m]); hi_ = std::max(hi_, c->nev[m]); }
+            if (lo_ > 0 && (int64_t)hi_ <= 8 * (int64_t)lo_) impl = 2;
+        }
+        c->tally_impl = impl;
+        if (c->K_auto) c->K = impl == 2 ? 32 : c->K_flat;
+    }
     // rows already in the table (event-range split: swept by sw_cansee_range or imported): no sweep, the round
     // loop still waits for whatever the sweep stream has in flight (imports, repairs)
     bool preswept = false;
@@ -1834,6 +1851,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         *dst = static_cast<std::remove_pointer_t<decltype(dst)>>(v);
     };
     int graph = c->use_graph ? 1 : 0;
+    c->K_auto = !(getenv("SW_TALLY_K") && *getenv("SW_TALLY_K"));
+    c->tally_auto = !(getenv("SW_TALLY_IMPL") && *getenv("SW_TALLY_IMPL"));
     knob("SW_TALLY_K", 1, 63, &c->K);             // (rounded to a multiple of 4 and capped at 60 below: a member's row of the candidate table has 64 columns)
     knob("SW_BAND", 64, 1 << 28, &c->NEARCAP);
     knob("SW_BAND_MAX", 64, 1 << 28, &c->MCAP);
@@ -1881,6 +1900,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     // npad*K waves, 4 per workgroup (npad is a multiple of 64 anyway); a member's row of the candidate
     // table has 64 slots and slot 0 is the window header, so at most 60 candidates after rounding
     c->K = std::min((c->K + 3) & ~3, 60);
+    c->K_flat = c->K;
     auto bail = [&](int rc) { g_create_error = c->err; sw_destroy(c); return rc; };
 #define CCHK(expr) do { int rc_ = (expr); if (rc_ != SW_OK) return bail(rc_); } while (0)
 #define CHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, SW_EIO, "%s: %s", #expr, hipGetErrorString(e_)); return bail(SW_EIO); } } while (0)
