@@ -250,14 +250,16 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        new_c = one_step(i)
-    barrier()
-    dt = rep.max_over_ranks(time.perf_counter() - t0)
+    last = {}
+
+    def timed_step(i):
+        last["new_c"] = one_step(args.warmup + i)
+
+    # EXACTLY `steps` steps between barrier + device synchronisation on both sides, the MAX over ranks (replicas.Replicas.timed)
+    dt = rep.timed(timed_step, args.steps, sync=torch.cuda.synchronize)
+    new_c = last["new_c"]
     ms_per_step = dt / args.steps * 1e3
-    value = world * N * args.steps / dt
+    value = rep.aggregate_throughput(N, args.steps, dt)   # events all ranks processed / the slowest rank's time
 
     # ---- two passes at once on ONE GPU (two contexts, two host threads): how much of the chip one latency-bound pass leaves
     # idle.  Reported next to `value`, never as `value`: a node divides ONE hashgraph, and ms_per_step is that pass's latency.

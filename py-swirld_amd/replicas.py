@@ -1,10 +1,9 @@
-"""Multi-GPU driver helpers.  The hot path does not shard across GPUs (DESIGN.md §(e):
-divide_rounds is a dependency chain over the whole DAG, and at ~20 ms per million events
-any per-round collective would cost more than the work it saves), so N GPUs run N
-independent replicas — one hashgraph view per GPU, which is also what a deployment has
-(every member holds its own view).  There is no data-path collective; torch.distributed
-(RCCL on GPUs, gloo in the CPU tests) is used only to line the replicas up and to take the
-maximum of their times."""
+"""Multi-GPU driver helpers of bench.py: the torchrun environment, the timed region (barrier + device
+synchronisation on both sides, max over ranks) and the whole-job aggregate.  `value` of a multi-GPU bench line is N
+independent replicas — one hashgraph view per GPU, which is what a deployment has (every member holds its own view);
+the one-hashgraph split (partition.StrongSplit: event-range can_see sweeps, RCCL row broadcasts, partitioned
+decide_fame) is timed next to it as `value_strong` (DESIGN.md §8 says why it cannot win).  torch.distributed is RCCL
+on GPUs, gloo in the CPU tests."""
 import os
 import time
 
