@@ -330,6 +330,7 @@ def main():
     new_c_prof = h.decide_fame()
     tm = h.timings()
     c1 = h.counters()
+    tally_name = h.tally_kernel   # the step-3 kernel THIS pass used (the library chooses per call, DESIGN.md §4 "Which tally")
     h.set_profiling(False)
     t_fo = time.perf_counter()
     ordered = h.find_order(new_c_prof)   # N1 (outside the metric): reported for information only
@@ -370,9 +371,10 @@ def main():
         fam(cs_name, tm["cansee_launches"], tm["cansee_kernel_ms"], 12 * n * (N - n), "hbm", cs_note),
         fam("k_resolve_band", tm["resolve_launches"], tm["resolve_ms"], cd["band_events"] * (4 * n + n // 8), "hbm/L2",
             "4n B read + n/8 B written per band event; the replicated resolve step (latency) dominates its time"),
-        fam("k_tally_bits", tm["tally_launches"], tm["tally_ms"], cd["tally_evals"] * (4 * n + n * n // 8 + 8), "L2",
-            "one can_see row + n gathered n-bit masks per evaluation; the gathers hit the L2-resident band table, "
-            "so the rate is an L2-gather rate, not HBM"),
+        fam(tally_name, tm["tally_launches"], tm["tally_ms"], cd["tally_evals"] * (4 * n + n * n // 8 + 8), "L2",
+            "one can_see row + n gathered n-bit masks per evaluation (%d evaluations this pass%s); the gathers hit the "
+            "L2-resident band table, so the rate is an L2-gather rate, not HBM"
+            % (cd["tally_evals"], ": the two-level search evaluates only the slots it probes" if tally_name == "k_tally_tree" else "")),
         fam("k_elections", 1, tm["elections_ms"], cd["majority_evals"] * (n // 8), "L2/LDS"),
     ]
     dom = max(kernels, key=lambda k: k["total_ms"])
@@ -382,9 +384,9 @@ def main():
     # (round loop: iterations that did work; finalize / voter masks: one launch per sub-batch)
     hbm_pmc = None
     if traffic:
-        per_pass = {cs_name: tm["cansee_launches"], "k_resolve_band": cd["round_iterations"], "k_tally_bits": cd["round_iterations"],
+        per_pass = {cs_name: tm["cansee_launches"], "k_resolve_band": cd["round_iterations"], tally_name: cd["round_iterations"],
                     "k_elections": 1, "k_voter_masks_bits": tm["cansee_launches"], "k_finalize_events": tm["cansee_launches"]}
-        if all(traffic.get(k) is not None for k in (cs_name, "k_resolve_band", "k_tally_bits")):
+        if all(traffic.get(k) is not None for k in (cs_name, "k_resolve_band", tally_name)):
             hbm_pmc = int(sum(traffic.get(k, 0) * v for k, v in per_pass.items()))
     roofline = {
         "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": PEAK_GBPS,

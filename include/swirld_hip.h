@@ -237,6 +237,11 @@ int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 /* The same for a caller built against another version of this header: copies min(out_bytes, sizeof(sw_counters))
  * bytes (fields are only ever appended), so a shorter struct is never overrun and a longer one keeps its tail. */
 int sw_get_counters_sized(sw_ctx* ctx, void* out, size_t out_bytes);
+/* Which step-3 kernel of the round loop the most recent sw_divide_rounds used: 0 = k_tally (column lanes, stake-weighted
+ * or SW_TALLY_IMPL=0), 1 = k_tally_bits (one wave per candidate slot), 2 = k_tally_tree (one workgroup per member, two-level
+ * search).  Without SW_TALLY_IMPL the library chooses per call (DESIGN.md §4 "Which tally"); measurement tools name the
+ * kernel they price by this.  No reference counterpart. */
+int sw_get_tally_impl(const sw_ctx* ctx);
 
 /* Per-phase GPU time of the most recent divide_rounds / decide_fame call, measured with
  * hipEvents on the context's own stream (ms).  Enabled by sw_set_profiling(ctx, 1). */

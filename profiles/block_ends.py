@@ -36,6 +36,9 @@ for kk, name in ((0, "k_resolve_band"), (1, "tally kernel")):
         base = v.min()
         rows.append([np.median(v) - base, np.percentile(v, 90) - base, np.percentile(v, 99) - base, v.max() - base, m.sum()])
         last_ids.append(int(np.flatnonzero(m)[np.argmax(v)]))
+    if not rows:
+        print("%s: no workgroup stamps (k_tally_tree does not stamp: pin SW_TALLY_IMPL=1 to see k_tally_bits)" % name)
+        continue
     r = np.array(rows, float)
     print("%s: %d iterations, %d workgroups stamped; end times after the FIRST workgroup done (us): median %.2f  p90 %.2f  p99 %.2f  last %.2f"
           % (name, len(r), int(r[:, 4].mean()), *(r[:, :4].mean(axis=0) / 100)))

@@ -48,6 +48,7 @@ SIGNATURES = {
     "sw_decide_fame_partial": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "sw_commit_fame": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "sw_row_stride": (C.c_int, [_P]),
+    "sw_get_tally_impl": (C.c_int, [_P]),
     "sw_cansee_range": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "sw_cansee_repair": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "sw_export_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),

@@ -218,6 +218,13 @@ class Hashgraph:
         self._chk(self._L.sw_get_counters_sized(self._h, C.byref(c), C.sizeof(c)))
         return {k: int(getattr(c, k)) for k, _ in Counters._fields_}
 
+    TALLY_KERNELS = ("k_tally", "k_tally_bits", "k_tally_tree")
+
+    @property
+    def tally_kernel(self):
+        """Name of the step-3 kernel of the round loop the most recent divide_rounds used (sw_get_tally_impl)."""
+        return self.TALLY_KERNELS[self._chk(self._L.sw_get_tally_impl(self._h))]
+
     def set_profiling(self, enable=True):
         self._chk(self._L.sw_set_profiling(self._h, 1 if enable else 0))
 

@@ -98,7 +98,7 @@ def test_committed_measurement_fixtures_bench_reads():
     from conftest import ROOT
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         tr = json.load(f)
-    assert tr["commit"] and tr["kernels"]["k_cansee_chunks"] > 0 and tr["kernels"]["k_tally_bits"] > 0
+    assert tr["commit"] and tr["kernels"]["k_cansee_chunks"] > 0 and tr["kernels"]["k_tally_tree"] > 0
     # the counter passes must have been taken on THIS tree's kernels: the file carries the SHA-256 of
     # csrc/kernels.hip.h it was measured on; bench.py quotes nothing from a stale file, and this test says so loudly
     import hashlib
