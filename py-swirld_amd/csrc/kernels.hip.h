@@ -2395,172 +2395,35 @@ k_elections(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsig
 }
 
 
-// The same elections with NW threads per candidate (selected with SW_ELECT_IMPL=1, npad * NW <= 1024):
-// thread (j, cx) tallies the 64 voters of mask word j for candidate cx, so a level is a quarter of
-// the dependent chain and four times the waves; the vote words, the first decider of each word
-// and the voter counts are exchanged through LDS, and every thread of a candidate takes the same
-// decision (thread j = 0 records it).  The whole round of voters is staged at once.
-template <int NW, bool UNIT>
-__global__ void __launch_bounds__(1024)
-k_elections_split(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsigned char* __restrict__ coin,
+// The same elections with NW threads per candidate (SW_ELECT_IMPL=1, the default for 128 members and more): thread (j, cx)
+// tallies the 64 voters of mask word j for candidate cx, so a level is 1/NW of the dependent chain and NW times the waves.
+// A workgroup holds CG candidates of ONE round (CG * NW threads), a round is npad / CG workgroups: at 256 members two of 512
+// threads (323 rounds x 1024 threads left 67 CUs with twice the work of the others), at 1024 members sixteen of 1024.
+//   * the voters' masks of a level are staged in LDS up to 256 members (8 KB), read from global memory beyond (a round of
+//     them is 128 KB at 1024 members; the word a wave reads is the same for all its lanes);
+//   * what depends on the voter only is computed once per level, not once per (voter, candidate): its total `tot` (the
+//     popcount / stake of its mask), kept as the two thresholds the vote is compared with —
+//         v  = !(no > yes)        <=>  yes >= ceil(tot / 2)
+//         3 * max(yes, no) > 2T   <=>  yes >= thr3  or  yes <= tot - thr3,   thr3 = floor(2T / 3) + 1
+//     (swirld.py:24-27, 260-262) — which leaves NW and-popcounts and four compares per pair;
+//   * the first decider (smallest event index among the voters with a supermajority, swirld.py:263) is a min over the
+//     packed key (event << 1 | vote); the vote words and keys of the NW threads of a candidate are exchanged through LDS and
+//     every one of them takes the same decision (thread j = 0 records it);
+//   * what concerns the ROUND — "every witness decided, at least one of them in this call" (swirld.py:274-277) — is agreed
+//     by the workgroups of the round through three words in `rsc` (zeroed by the host): open witnesses, decided flag,
+//     arrival ticket; the last one to arrive publishes it.
+// Round 4 (profiles/r04o_*): 230 us -> see DESIGN.md §4 for the 256 x 1 M elections; one thread per candidate (k_elections)
+// took 6.7 ms per pass at 1024 members / 2 M events.
+template <int NW, bool UNIT, int CG>
+__global__ void __launch_bounds__(CG * NW)
+k_elections_tiled(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsigned char* __restrict__ coin,
                   const uint32_t* __restrict__ stake, uint32_t tot2, int coin_period, int max_c, int R,
-                  int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc, int* dec_call, int* dec_by, int call_idx, int part, int nparts) {
-    const int r = max_c + part + nparts * (int)blockIdx.x;  // candidate rounds of this part (1 part: all of them)
-    const int tid = threadIdx.x;
-    const int j = tid / npad, cx = tid - j * npad;  // npad is a multiple of 64: j is uniform in a wave
-    const int x = wit[(size_t)r * npad + cx];
-    {
-        const int nw_r = __syncthreads_count(j == 0 && x >= 0);
-        if (tid == 0 && r > max_c) atomicAdd(&fc->voter_evals, (u64)nw_r);
-    }
-    if (cons[r]) return;
-    __shared__ int s_wv[64 * NW];
-    __shared__ u64 s_m[64 * NW * NW];
-    __shared__ u64 s_V[NW][64 * NW];
-    __shared__ int s_bi[NW][64 * NW];
-    __shared__ int s_bv[NW][64 * NW];
-    __shared__ int s_nv[NW];
-    __shared__ u64 s_p2[16];
-    bool active = x >= 0 && fam[(size_t)r * npad + cx] < 0;
-    u64 V[NW];
-#pragma unroll
-    for (int jj = 0; jj < NW; ++jj) V[jj] = 0;
-    int any_decided = 0;
-    u64 p2 = 0, cvotes = 0, cflips = 0;
-    for (int d = 1; r + d < R; ++d) {
-        if (!__syncthreads_or(active)) break;  // also: every read of the previous level is done
-        const int rv = r + d;
-        const int* wv_row = wit + (size_t)rv * npad;
-        const u64* sw_row = Sw + (size_t)rv * npad * NW;
-        const bool coin_round = (d % coin_period) == 0;
-        s_m[tid] = sw_row[tid];  // blockDim = npad * NW = words of the round's voter masks
-        if (tid < npad) s_wv[tid] = wv_row[tid];
-        __syncthreads();
-        u64 acc = 0;
-        int best_idx = SW_INF, best_v = 0, nv = 0;
-        for (int ci = 0; ci < 64; ++ci) {
-            const int c = j * 64 + ci;
-            const int wv = s_wv[c];  // uniform in the wave
-            if (wv < 0) continue;
-            ++nv;
-            const u64* m = s_m + c * NW;
-            int bitv;
-            if (d == 1) {
-                bitv = (int)((m[cx >> 6] >> (cx & 63)) & 1ull);  // x in s (swirld.py:258)
-            } else {
-                uint32_t yes = 0, tot = 0;
-                if (UNIT) {
-#pragma unroll
-                    for (int jj = 0; jj < NW; ++jj) {
-                        const u64 mm = m[jj];
-                        yes += __popcll(mm & V[jj]);
-                        tot += __popcll(mm);
-                    }
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < NW; ++jj) {
-                        u64 mm = m[jj];
-                        while (mm) {
-                            const int b = __ffsll((long long)mm) - 1;
-                            mm &= mm - 1;
-                            const uint32_t sk = stake[jj * 64 + b];
-                            tot += sk;
-                            if ((V[jj] >> b) & 1ull) yes += sk;
-                        }
-                    }
-                }
-                const uint32_t no = tot - yes;
-                const int v = !(no > yes);  // majority(): tie -> True (swirld.py:24-27)
-                const uint32_t t = v ? yes : no;
-                const bool sm = 3u * t > tot2;
-                if (!coin_round) {
-                    if (sm && wv < best_idx) { best_idx = wv; best_v = v; }
-                    bitv = v;
-                } else {
-                    bitv = sm ? v : (int)coin[wv];  // swirld.py:267-272
-                    if (active) { ++cvotes; cflips += !sm; }
-                }
-            }
-            acc |= (u64)bitv << ci;
-        }
-        s_V[j][cx] = acc;
-        s_bi[j][cx] = best_idx;
-        s_bv[j][cx] = best_v;
-        if (cx == 0) s_nv[j] = nv;
-        __syncthreads();
-        int nvoters = 0;
-        best_idx = SW_INF;
-        best_v = 0;
-#pragma unroll
-        for (int jj = 0; jj < NW; ++jj) {
-            V[jj] = s_V[jj][cx];
-            nvoters += s_nv[jj];
-            const int bi = s_bi[jj][cx];
-            if (bi < best_idx) { best_idx = bi; best_v = s_bv[jj][cx]; }
-        }
-        if (active && d >= 2) {
-            if (!coin_round && best_idx != SW_INF) {
-                active = false;
-                any_decided = 1;
-                if (j == 0) {
-                    fam[(size_t)r * npad + cx] = (signed char)best_v;  // swirld.py:263
-                    dec_call[(size_t)r * npad + cx] = call_idx;        // which decide_fame() call decided x, and which voter
-                    dec_by[(size_t)r * npad + cx] = best_idx;
-                    int le = 0;  // voters after the first decider never evaluate x
-                    for (int c = 0; c < npad; ++c) {
-                        const int wv = s_wv[c];
-                        le += (wv >= 0 && wv <= best_idx);
-                    }
-                    p2 += le;
-                }
-            } else if (j == 0) {
-                p2 += nvoters;
-            }
-        }
-    }
-    const int x_open = j == 0 && x >= 0 && fam[(size_t)r * npad + cx] < 0;
-    const int n_open = __syncthreads_count(x_open);
-    const int dec = __syncthreads_or(any_decided);
-    if (tid == 0 && dec && n_open == 0) {  // swirld.py:274-277
-        newc[r] = 1;
-        cons[r] = 1;
-    }
-    {   // one atomic per workgroup and counter
-        u64 t = p2, tv = cvotes, tf = cflips;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            t += (u64)__shfl_xor((long long)t, off);
-            tv += (u64)__shfl_xor((long long)tv, off);
-            tf += (u64)__shfl_xor((long long)tf, off);
-        }
-        __shared__ u64 s_cv[16], s_cf[16];
-        if ((tid & 63) == 0) { s_p2[tid >> 6] = t; s_cv[tid >> 6] = tv; s_cf[tid >> 6] = tf; }
-        __syncthreads();
-        if (tid == 0) {
-            u64 tot = 0, totv = 0, totf = 0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot += s_p2[w]; totv += s_cv[w]; totf += s_cf[w]; }
-            if (tot) atomicAdd(&fc->majority_evals, tot);
-            if (totv) atomicAdd(&fc->coin_votes, totv);
-            if (totf) atomicAdd(&fc->coin_flips, totf);
-        }
-    }
-}
-
-// ... and for member counts beyond 256 (npad * NW > 1024 threads): the candidates of a round are split over
-// npad / CG workgroups of CG = 1024 / NW candidates x NW threads.  The voters' masks are read from global memory
-// (a round of them is 128 KB at 1024 members: no LDS staging; the word a wave reads is the same for all its
-// lanes), the per-level exchange stays in LDS, and what concerns the ROUND — "every witness decided, at least one
-// of them in this call" (swirld.py:274-277) — is agreed through three words per round in `rsc` (zeroed by the
-// host): open witnesses, decided flag, arrival ticket; the last workgroup of the round to arrive publishes it.
-// One thread per candidate (k_elections) took 6.7 ms per pass at 1024 members / 2 M events.
-template <int NW, bool UNIT>
-__global__ void __launch_bounds__(1024)
-k_elections_wide(const int* __restrict__ wit, const u64* __restrict__ Sw, const unsigned char* __restrict__ coin,
-                 const uint32_t* __restrict__ stake, uint32_t tot2, int coin_period, int max_c, int R,
-                 int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc, int* dec_call, int* dec_by,
-                 int call_idx, int part, int nparts, int* rsc) {
-    constexpr int CG = 1024 / NW;          // candidates per workgroup
-    const int GB = npad / CG;              // workgroups per round
+                  int npad, signed char* fam, unsigned char* cons, unsigned char* newc, FameCounters* fc, int* dec_call, int* dec_by,
+                  int call_idx, int part, int nparts, int* rsc) {
+    constexpr int NT = CG * NW;
+    constexpr bool STAGE = NW <= 4;          // voters' masks of a level in LDS
+    static_assert(CG % 64 == 0 && NT <= 1024 && (64 * NW) % CG == 0, "a wave has one j; a round is a whole number of workgroups");
+    constexpr int GB = 64 * NW / CG;         // workgroups per round (npad = 64 NW)
     const int rb = (int)blockIdx.x / GB, g = (int)blockIdx.x - rb * GB;
     const int r = max_c + part + nparts * rb;
     const int tid = threadIdx.x;
@@ -2573,11 +2436,14 @@ k_elections_wide(const int* __restrict__ wit, const u64* __restrict__ Sw, const 
     }
     if (cons[r]) return;
     __shared__ int s_wv[64 * NW];
+    __shared__ int s_half[64 * NW];   // ceil(tot / 2) of the voter
+    __shared__ int s_lot[64 * NW];    // tot - thr3 (signed)
+    __shared__ u64 s_m[STAGE ? 64 * NW * NW : 1];
     __shared__ u64 s_V[NW][CG];
-    __shared__ int s_bi[NW][CG];
-    __shared__ int s_bv[NW][CG];
+    __shared__ uint32_t s_key[NW][CG];
     __shared__ int s_nv[NW];
     __shared__ u64 s_p2[16], s_cv[16], s_cf[16];
+    const uint32_t thr3 = tot2 / 3u + 1u;
     bool active = x >= 0 && fam[(size_t)r * npad + cx] < 0;
     u64 V[NW];
 #pragma unroll
@@ -2590,47 +2456,66 @@ k_elections_wide(const int* __restrict__ wit, const u64* __restrict__ Sw, const 
         const int* wv_row = wit + (size_t)rv * npad;
         const u64* sw_row = Sw + (size_t)rv * npad * NW;
         const bool coin_round = (d % coin_period) == 0;
-        for (int i = tid; i < npad; i += 1024) s_wv[i] = wv_row[i];
+        for (int i = tid; i < 64 * NW; i += NT) s_wv[i] = wv_row[i];
+        if (STAGE)
+            for (int i = tid; i < 64 * NW * NW; i += NT) s_m[i] = sw_row[i];
         __syncthreads();
+        if (d >= 2) {   // per voter, once: the total of its mask as the two thresholds
+            for (int i = tid; i < 64 * NW; i += NT) {
+                uint32_t tot = 0;
+                if (s_wv[i] >= 0) {   // (the mask row of a member without a witness in this round is never read)
+                    const u64* m = STAGE ? s_m + i * NW : sw_row + (size_t)i * NW;
+#pragma unroll
+                    for (int jj = 0; jj < NW; ++jj) {
+                        u64 mm = m[jj];
+                        if (UNIT) {
+                            tot += __popcll(mm);
+                        } else {
+                            while (mm) {
+                                const int b = __ffsll((long long)mm) - 1;
+                                mm &= mm - 1;
+                                tot += stake[jj * 64 + b];
+                            }
+                        }
+                    }
+                }
+                s_half[i] = (int)((tot + 1u) >> 1);
+                s_lot[i] = (int)tot - (int)thr3;
+            }
+            __syncthreads();
+        }
         u64 acc = 0;
-        int best_idx = SW_INF, best_v = 0, nv = 0;
+        uint32_t key = 0xffffffffu;
+        int nv = 0;
         for (int ci = 0; ci < 64; ++ci) {
             const int c = j * 64 + ci;
             const int wv = s_wv[c];  // uniform in the wave
             if (wv < 0) continue;
             ++nv;
-            const u64* m = sw_row + (size_t)c * NW;   // (the same words for every lane of the wave)
+            const u64* m = STAGE ? s_m + c * NW : sw_row + (size_t)c * NW;   // (the same words for every lane of the wave)
             int bitv;
             if (d == 1) {
                 bitv = (int)((m[cx >> 6] >> (cx & 63)) & 1ull);  // x in s (swirld.py:258)
             } else {
-                uint32_t yes = 0, tot = 0;
-                if (UNIT) {
+                uint32_t yes = 0;
 #pragma unroll
-                    for (int jj = 0; jj < NW; ++jj) {
-                        const u64 mm = m[jj];
-                        yes += __popcll(mm & V[jj]);
-                        tot += __popcll(mm);
-                    }
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < NW; ++jj) {
-                        u64 mm = m[jj];
+                for (int jj = 0; jj < NW; ++jj) {
+                    u64 mm = m[jj] & V[jj];
+                    if (UNIT) {
+                        yes += __popcll(mm);
+                    } else {
                         while (mm) {
                             const int b = __ffsll((long long)mm) - 1;
                             mm &= mm - 1;
-                            const uint32_t sk = stake[jj * 64 + b];
-                            tot += sk;
-                            if ((V[jj] >> b) & 1ull) yes += sk;
+                            yes += stake[jj * 64 + b];
                         }
                     }
                 }
-                const uint32_t no = tot - yes;
-                const int v = !(no > yes);  // majority(): tie -> True (swirld.py:24-27)
-                const uint32_t t = v ? yes : no;
-                const bool sm = 3u * t > tot2;
+                const int v = yes >= (uint32_t)s_half[c];                 // majority(): tie -> True (swirld.py:24-27)
+                const bool sm = yes >= thr3 || (int)yes <= s_lot[c];      // the winning side holds more than 2/3 of the stake
                 if (!coin_round) {
-                    if (sm && wv < best_idx) { best_idx = wv; best_v = v; }
+                    const uint32_t k = sm ? (((uint32_t)wv << 1) | (uint32_t)v) : 0xffffffffu;
+                    key = k < key ? k : key;
                     bitv = v;
                 } else {
                     bitv = sm ? v : (int)coin[wv];  // swirld.py:267-272
@@ -2640,52 +2525,53 @@ k_elections_wide(const int* __restrict__ wit, const u64* __restrict__ Sw, const 
             acc |= (u64)bitv << ci;
         }
         s_V[j][cxl] = acc;
-        s_bi[j][cxl] = best_idx;
-        s_bv[j][cxl] = best_v;
+        s_key[j][cxl] = key;
         if (cxl == 0) s_nv[j] = nv;
         __syncthreads();
-        int nvoters = 0;
-        best_idx = SW_INF;
-        best_v = 0;
+        key = 0xffffffffu;
 #pragma unroll
         for (int jj = 0; jj < NW; ++jj) {
             V[jj] = s_V[jj][cxl];
-            nvoters += s_nv[jj];
-            const int bi = s_bi[jj][cxl];
-            if (bi < best_idx) { best_idx = bi; best_v = s_bv[jj][cxl]; }
+            const uint32_t k = s_key[jj][cxl];
+            key = k < key ? k : key;
         }
         if (active && d >= 2) {
-            if (!coin_round && best_idx != SW_INF) {
+            if (!coin_round && key != 0xffffffffu) {
+                const int best_idx = (int)(key >> 1);
                 active = false;
                 any_decided = 1;
                 if (j == 0) {
-                    fam[(size_t)r * npad + cx] = (signed char)best_v;  // swirld.py:263
-                    dec_call[(size_t)r * npad + cx] = call_idx;        // which decide_fame() call decided x, and which voter
+                    fam[(size_t)r * npad + cx] = (signed char)(key & 1u);  // swirld.py:263
+                    dec_call[(size_t)r * npad + cx] = call_idx;            // which decide_fame() call decided x, and which voter
                     dec_by[(size_t)r * npad + cx] = best_idx;
-                    int le = 0;  // voters after the first decider never evaluate x
-                    for (int c = 0; c < npad; ++c) {
-                        const int wv = s_wv[c];
-                        le += (wv >= 0 && wv <= best_idx);
-                    }
-                    p2 += le;
                 }
-            } else if (j == 0) {
-                p2 += nvoters;
+                int le = 0;  // voters after the first decider never evaluate x (each of the NW threads counts its own word)
+                for (int ci = 0; ci < 64; ++ci) {
+                    const int wv = s_wv[j * 64 + ci];
+                    le += (wv >= 0 && wv <= best_idx);
+                }
+                p2 += le;
+            } else {
+                p2 += nv;
             }
         }
     }
     const int x_open = j == 0 && x >= 0 && active;   // (`active` mirrors fam < 0 for this thread's candidate)
     const int n_open = __syncthreads_count(x_open);
     const int dec = __syncthreads_or(any_decided);
-    if (tid == 0) {  // swirld.py:274-277, over the workgroups of the round
-        if (n_open) atomicAdd(&rsc[3 * r], n_open);
-        if (dec) atomicOr(&rsc[3 * r + 1], 1);
-        __threadfence();
-        if (atomicAdd(&rsc[3 * r + 2], 1) == GB - 1) {
+    if (tid == 0) {  // swirld.py:274-277
+        if (GB == 1) {
+            if (dec && n_open == 0) { newc[r] = 1; cons[r] = 1; }
+        } else {     // ... over the workgroups of the round
+            if (n_open) atomicAdd(&rsc[3 * r], n_open);
+            if (dec) atomicOr(&rsc[3 * r + 1], 1);
             __threadfence();
-            if (atomicAdd(&rsc[3 * r], 0) == 0 && atomicAdd(&rsc[3 * r + 1], 0) != 0) {
-                newc[r] = 1;
-                cons[r] = 1;
+            if (atomicAdd(&rsc[3 * r + 2], 1) == GB - 1) {
+                __threadfence();
+                if (atomicAdd(&rsc[3 * r], 0) == 0 && atomicAdd(&rsc[3 * r + 1], 0) != 0) {
+                    newc[r] = 1;
+                    cons[r] = 1;
+                }
             }
         }
     }
@@ -2701,7 +2587,7 @@ k_elections_wide(const int* __restrict__ wit, const u64* __restrict__ Sw, const 
         __syncthreads();
         if (tid == 0) {
             u64 tot = 0, totv = 0, totf = 0;
-            for (int w = 0; w < 16; ++w) { tot += s_p2[w]; totv += s_cv[w]; totf += s_cf[w]; }
+            for (int w = 0; w < NT / 64; ++w) { tot += s_p2[w]; totv += s_cv[w]; totf += s_cf[w]; }
             if (tot) atomicAdd(&fc->majority_evals, tot);
             if (totv) atomicAdd(&fc->coin_votes, totv);
             if (totf) atomicAdd(&fc->coin_flips, totf);

@@ -170,7 +170,7 @@ struct sw_ctx {
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
-    DBuf<int32_t> d_rsc;   // [R][3] round-level agreement of k_elections_wide: open witnesses, decided flag, arrival ticket
+    DBuf<int32_t> d_rsc;   // [R][3] round-level agreement of k_elections_tiled: open witnesses, decided flag, arrival ticket
     DBuf<u64> d_found64;   // [2][npad] {event << 32 | slot << 26 | look-ahead} of the members' first passing candidates (LoopBufs::found64)
     // one device block read back with ONE copy per round-loop shot: loop state (x2), sweep error flag, per-member
     // front rounds; and its pinned host mirror
@@ -190,7 +190,8 @@ struct sw_ctx {
     // tuning
     int skip = 1;         // SW_SKIP: window offset of a fresh round (0 = off); 1 measured best at 256 members (310 vs 326 iterations)
     int gallop_after = 2; // SW_GALLOP: strided candidate windows after this many windows without a passing candidate (0 = never); 2 costs uniform gossip nothing (the first window passes there) and cuts hot-member hashgraphs from 2756 to ~200 iterations
-    int elect_impl = 1; // 1: NW threads per candidate where npad * NW <= 1024 (k_elections_split), 0: one thread per candidate
+    int elect_impl = 1; // 1: NW threads per candidate (k_elections_tiled, 128 members and more), 0: one thread per candidate
+    int elect_cg = 128; // SW_ELECT_CG (256 members): candidates per workgroup of k_elections_tiled — 64, 128 or 256
     int K = 28;        // candidates per member per tally launch: 7 waves per SIMD (the 8th slot is
                        // taken by the concurrent can_see sweep; 29+ costs a second wave generation)
     int MCAP = 0;      // largest band (events) the mask table can hold
@@ -204,6 +205,9 @@ struct sw_ctx {
     bool K_auto = true;       // SW_TALLY_K not set: 28 slots for the flat tally, 32 for the tree
     int K_flat = 28;
     int band_blocks = 512; // workgroups of the resolve+band kernel
+    int fin_blocks = 1024; // SW_FIN_BLOCKS: workgroups of a k_finalize_events launch that runs beside a round loop (profiles/r04q_*: 8192 of them
+                           // slow the loop's gathers down; 1024 with the early finalize below: 7.30 -> 7.16 ms per pass at 256 x 1 M, 69.7 -> 66.9 ms at 10 M)
+    int mid_pct = 88;      // SW_MID_PCT: where the last sub-batch's round loop is interrupted once for the early finalize (0 = never)
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
     // round-loop graph
@@ -877,7 +881,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
 
 template <int NW>
 int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, const int32_t* visible_len, float* tally_ms_out, int* tally_launches_out,
-                   const std::function<int()>* after_first_shot = nullptr) {
+                   const std::function<int()>* after_first_shot = nullptr, const std::function<int(const RState&)>* mid_loop = nullptr) {
     const int np = c->npad, K = c->K;
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
                        (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p);
@@ -897,6 +901,15 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         shot = std::max(2, (int)(pred * factor) + extra);
     }
     shot = std::min(shot, 4096) & ~1;
+    // `mid_loop` (the last sub-batch of a large call): the first shot stops `mid_pct` % of the way, the host looks at the loop
+    // state once — every event below the band of the round in progress has its final round by then — and hands it to the
+    // caller, which finalizes those events beside the rest of the loop instead of behind it; the rest of the prediction follows
+    int rest = 0;
+    if (mid_loop && shot >= 64 && c->mid_pct > 0) {
+        const int head = std::max(2, (int)((int64_t)shot * c->mid_pct / 100) & ~1);
+        rest = std::max(2, (shot - head) & ~1);
+        shot = head;
+    }
     for (;;) {
         CHK(ensure_rounds(c, c->R + launched + shot + 4));
         CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr, c->profiling ? &resolve_spans : nullptr));
@@ -919,6 +932,11 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
         if ((int64_t)launched > (int64_t)c->max_height + 2 + c->N / K + 4096)
             return fail(c, SW_EIO, "round loop did not terminate after %d iterations (r=%d)", launched, st.r);
+        if (rest) {
+            CHK((*mid_loop)(st));
+            shot = rest;
+            rest = 0;
+        } else
         shot = launched < 8 ? 2 : (launched < 48 ? 8 : 4);
     }
     if (n_new_events >= 4096) {  // keep the rate estimate to runs where it means something
@@ -1247,7 +1265,24 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         const int64_t dbg_it0 = c->ctr.round_iterations;
         if (dbg_t) (void)hipStreamSynchronize(c->stream);  // separates "waiting for the sweep" from the loop itself
         const auto dbg_t1 = std::chrono::steady_clock::now();
-        CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], c->d_bounds.p + (size_t)(i + 1) * np, &tally_ms, &tally_launches, &pending_aux));
+        // the last sub-batch has no later loop to hide its finalize behind: most of it runs beside the end of its own loop
+        int64_t fin_from = cut[i];
+        const std::function<int(const RState&)> early_fin = [c, np, &fin_from, limit, &pending_aux](const RState& st) -> int {
+            CHK(pending_aux());   // (the previous sub-batch's launches go first: same stream, same order as without the early part)
+            const int64_t upto = std::min<int64_t>(st.mlo, limit);
+            if (st.iter <= 0 || upto < fin_from + 16384) return SW_OK;
+            // events below the band of round st.r: round <= st.r - 1, rows 0 .. st.r of the table are committed and final
+            CHK(ensure_rounds(c, st.r + 2));
+            const int64_t k1 = upto - fin_from;
+            hipLaunchKernelGGL(k_finalize_events<NW>, dim3((unsigned)std::min<int64_t>((k1 + 3) / 4, c->fin_blocks)), dim3(256), 0, c->stream_aux, (const int*)c->d_L.p,
+                               (const int*)c->d_cr.p, (const int*)c->d_lo.p, st.r + 1, (int)fin_from, (int)k1, c->d_round.p, c->d_S.p, np);
+            c->ctr.kernel_launches++;
+            fin_from = upto;
+            return SW_OK;
+        };
+        const bool split_fin = i == S - 1 && cut[i + 1] - cut[i] >= 65536;
+        CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], c->d_bounds.p + (size_t)(i + 1) * np, &tally_ms, &tally_launches, &pending_aux,
+                               split_fin ? &early_fin : nullptr));
         CHK(pending_aux());   // (a loop that returned before its first shot — never — would have left it undone)
         if (dbg_t) {
             const auto dbg_t2 = std::chrono::steady_clock::now();
@@ -1286,17 +1321,20 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         // this loop's kernels, which the aux stream learns from an event recorded here).
         {
             CHK(ensure_rounds(c, R + 2));
-            const int64_t a0 = cut[i], k0 = cut[i + 1] - cut[i];
+            const int64_t a0 = fin_from, k0 = cut[i + 1] - fin_from;   // (the early part of the last sub-batch is done)
             const int rs_ = r_start, i_ = i;
             HIPCHK(c, hipEventRecord(c->ev_loop_done, c->stream));
             aux_armed = true;
-            pending_aux = [c, np, R, a0, k0, rs_, i_, &fin_t0, &aux_armed]() -> int {
+            const int S_ = S;
+            pending_aux = [c, np, R, a0, k0, rs_, i_, S_, &fin_t0, &aux_armed]() -> int {
                 if (!aux_armed) return SW_OK;
                 aux_armed = false;
                 hipStream_t ax = c->stream_aux;
                 HIPCHK(c, hipStreamWaitEvent(ax, c->ev_loop_done, 0));
                 if (i_ == 0 && c->profiling) { fin_t0 = next_event(c); (void)hipEventRecord(fin_t0, ax); }
-                const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, 8192);
+                // (a finalize that runs beside the next round loop is throttled: fewer workgroups, less pressure on the loop's gathers;
+                // the last one has nothing to hide behind and takes the whole GPU)
+                const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, i_ == S_ - 1 ? 8192 : c->fin_blocks);
                 hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, ax, (const int*)c->d_L.p,
                                    (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)a0, (int)k0, c->d_round.p, c->d_S.p, np);
                 const int total = (R - rs_) * np;
@@ -1377,20 +1415,23 @@ int fame_launch(sw_ctx* c, int max_c, int part, int nparts, Span* sp_el) {
         bool split_done = false;
 #define SW_ELECT_ARGS (const int*)c->d_wit.p, (const u64*)c->d_Sw.p, (const unsigned char*)c->d_coin.p, (const uint32_t*)c->d_stake.p, \
                       tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p + sizeof(FameCounters), c->d_fc, c->d_dec_call.p, c->d_dec_by.p, call_idx, part, nparts
-        if constexpr (NW >= 2 && NW <= 4) {  // NW threads per candidate (see k_elections_split): npad * NW <= 1024
-            if (c->elect_impl == 1) {
-                if (c->unit_stake) hipLaunchKernelGGL((k_elections_split<NW, true>), dim3(nblk), dim3(np * NW), 0, c->stream, SW_ELECT_ARGS);
-                else hipLaunchKernelGGL((k_elections_split<NW, false>), dim3(nblk), dim3(np * NW), 0, c->stream, SW_ELECT_ARGS);
-                split_done = true;
-            }
-        }
-        if constexpr (NW >= 8) {  // beyond 256 members: the candidates of a round over npad * NW / 1024 workgroups (k_elections_wide)
+        if constexpr (NW >= 2) {  // NW threads per candidate, a round as 64 NW / CG workgroups of CG candidates (k_elections_tiled)
             if (c->elect_impl == 1) {
                 CHK(dgrow(c, c->d_rsc, (size_t)3 * c->Rcap, 0));
                 HIPCHK(c, hipMemsetAsync(c->d_rsc.p, 0, (size_t)3 * R * sizeof(int32_t), c->stream));
-                const int gb = np * NW / 1024;
-                if (c->unit_stake) hipLaunchKernelGGL((k_elections_wide<NW, true>), dim3(nblk * gb), dim3(1024), 0, c->stream, SW_ELECT_ARGS, c->d_rsc.p);
-                else hipLaunchKernelGGL((k_elections_wide<NW, false>), dim3(nblk * gb), dim3(1024), 0, c->stream, SW_ELECT_ARGS, c->d_rsc.p);
+#define SW_ELECT_TILED(CG_)                                                                                                             \
+    do {                                                                                                                                \
+        if (c->unit_stake) hipLaunchKernelGGL((k_elections_tiled<NW, true, CG_>), dim3(nblk * (64 * NW / (CG_))), dim3((CG_) * NW), 0, c->stream, SW_ELECT_ARGS, c->d_rsc.p);  \
+        else hipLaunchKernelGGL((k_elections_tiled<NW, false, CG_>), dim3(nblk * (64 * NW / (CG_))), dim3((CG_) * NW), 0, c->stream, SW_ELECT_ARGS, c->d_rsc.p);                \
+    } while (0)
+                if constexpr (NW == 2) SW_ELECT_TILED(128);
+                else if constexpr (NW == 4) {
+                    if (c->elect_cg == 64) SW_ELECT_TILED(64);
+                    else if (c->elect_cg == 256) SW_ELECT_TILED(256);
+                    else SW_ELECT_TILED(128);
+                } else if constexpr (NW == 8) SW_ELECT_TILED(128);
+                else SW_ELECT_TILED(64);
+#undef SW_ELECT_TILED
                 split_done = true;
             }
         }
@@ -1864,6 +1905,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (c->npad >= 1024) c->band_blocks = 256;
     knob("SW_BAND_BLOCKS", 1, 4096, &c->band_blocks);
     knob("SW_TALLY_PF", 0, 1, &c->tally_pf);
+    knob("SW_MID_PCT", 0, 99, &c->mid_pct);
+    knob("SW_FIN_BLOCKS", 64, 8192, &c->fin_blocks);
     knob("SW_PIPE", 1, 64, &c->pipe);
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
     knob("SW_CANSEE_IMPL", 2, 6, &c->cansee_impl);
@@ -1876,6 +1919,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->halo = 32 * (int64_t)c->npad;
     knob("SW_HALO", 0, 1 << 24, &c->halo);
     knob("SW_ELECT_IMPL", 0, 1, &c->elect_impl);
+    knob("SW_ELECT_CG", 64, 256, &c->elect_cg);
+    if (c->elect_cg != 64 && c->elect_cg != 128 && c->elect_cg != 256) knob_err = "SW_ELECT_CG: 64, 128 or 256";
     knob("SW_GALLOP", 0, 255, &c->gallop_after);
     knob("SW_SKIP", 0, 32, &c->skip);
     knob("SW_RING_H", 0, 64, &c->ring_H_req);      // ring depth of the level-bucketed sweep (0 = automatic)

@@ -223,7 +223,10 @@ class Hashgraph:
     @property
     def tally_kernel(self):
         """Name of the step-3 kernel of the round loop the most recent divide_rounds used (sw_get_tally_impl)."""
-        return self.TALLY_KERNELS[self._chk(self._L.sw_get_tally_impl(self._h))]
+        i = int(self._L.sw_get_tally_impl(self._h))
+        if not 0 <= i < len(self.TALLY_KERNELS):
+            raise SwirldHipError(i, "sw_get_tally_impl")
+        return self.TALLY_KERNELS[i]
 
     def set_profiling(self, enable=True):
         self._chk(self._L.sw_set_profiling(self._h, 1 if enable else 0))

@@ -274,12 +274,14 @@ def test_kernel_variants_agree(pkg, monkeypatch, cansee, tally, ring_h):
         h.close()
 
 
-@pytest.mark.parametrize("elect", ["0", "1"])
-def test_election_kernel_variants_agree(pkg, monkeypatch, elect):
-    """One thread per candidate (0) and NW threads per candidate (1, the default where
-    npad * NW <= 1024) against the oracle: decisions, consensus rounds and the V / P2 counters,
-    batch and incremental schedules, four generator modes."""
+@pytest.mark.parametrize("elect,cg", [("0", None), ("1", None), ("1", "64"), ("1", "256")])
+def test_election_kernel_variants_agree(pkg, monkeypatch, elect, cg):
+    """One thread per candidate (0) and NW threads per candidate in tiles of CG candidates (1, k_elections_tiled: the
+    default from 128 members on; at 256 members a round is 4, 2 or 1 workgroups) against the oracle: decisions, consensus
+    rounds and the V / P2 counters, batch and incremental schedules, four generator modes."""
     monkeypatch.setenv("SW_ELECT_IMPL", elect)
+    if cg:
+        monkeypatch.setenv("SW_ELECT_CG", cg)
     for n, N, seed, mode, p0, p1, chunk in [(130, 14000, 75, 0, 0, 0, None), (256, 30000, 76, 2, 0.2, 0.05, 7000),
                                             (100, 9000, 77, 1, 0.02, 0, 1500), (200, 20000, 78, 3, 0.6, 0, None)]:
         stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
