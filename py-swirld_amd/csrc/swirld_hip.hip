@@ -1606,7 +1606,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         HIPCHK(c, hipMemcpyAsync(c->d_fw_ev.p, fw_ev.data(), fw_ev.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_fw_off.p, fw_off.data(), (nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_order_bounds, dim3(nr), dim3(np), 0, c->stream, (const int*)c->d_fw_ev.p, (const int*)c->d_fw_off.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const uint32_t*)c->d_stake.p, c->tot,
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_seq.p, (const uint32_t*)c->d_stake.p, c->tot,
                        (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, np, c->d_q.p);
     c->ctr.kernel_launches++;
     std::vector<int32_t> q((size_t)nr * np);
