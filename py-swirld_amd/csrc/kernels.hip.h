@@ -990,9 +990,11 @@ __device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v));
 // Start of a round-loop run: the loop state and the per-member buffers in ONE launch (a small
 // call would otherwise pay five separate copies / fills, ~10 us each).
 __global__ void __launch_bounds__(1024)
-k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len) {
+k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len, int eval_src) {
     // chain lengths visible to this run = the sub-batch's row of the cut table (already on the device)
     for (int i = threadIdx.x; i < npad; i += blockDim.x) { chain_len[i] = visible_len[i]; B.treecnt[i] = 0; }
+    if (eval_src)   // the previous run ended on an odd iteration: its exhaustion marks are in half 1, this run reads half 0
+        for (int i = threadIdx.x; i < npad; i += blockDim.x) { B.evalround[i] = B.evalround[npad + i]; B.evalpos[i] = B.evalpos[npad + i]; }
     if (threadIdx.x == 0) {
         RState t{};
         t.r = r_start;
@@ -3015,6 +3017,17 @@ k_sync_diff(const int* __restrict__ L, const int* __restrict__ ht, const int* __
     }
     pos_first[m] = p0;
     pos_end[m] = p1 > p0 ? p1 : p0;
+}
+
+// sw_rewind: every table of the voting state back to its initial value in ONE launch (eleven fills and memsets took
+// ~0.1 ms of every measured pass): blockIdx.y = the table, 32-bit words, grid-stride.
+struct RewindJob { int* p[12]; unsigned long long n[12]; int v[12]; };
+__global__ void k_rewind_fill(RewindJob J) {
+    int* p = J.p[blockIdx.y];
+    const size_t n = J.n[blockIdx.y];
+    const int v = J.v[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
 __global__ void k_fill_i32(int* p, size_t n, int v) {

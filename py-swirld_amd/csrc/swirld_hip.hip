@@ -204,6 +204,7 @@ struct sw_ctx {
     bool tally_auto = true;   // SW_TALLY_IMPL not set: large calls of ~256-member hashgraphs without strongly skewed activity use 2
     bool K_auto = true;       // SW_TALLY_K not set: 28 slots for the flat tally, 32 for the tree
     int K_flat = 28;
+    int eval_src = 0;      // which half of d_evalround / d_evalpos the last round-loop run left the members' exhaustion marks in
     int band_blocks = 512; // workgroups of the resolve+band kernel
     int fin_blocks = 1024; // SW_FIN_BLOCKS: workgroups of a k_finalize_events launch that runs beside a round loop (profiles/r04q_*: 8192 of them
                            // slow the loop's gathers down; 1024 with the early finalize below: 7.30 -> 7.16 ms per pass at 256 x 1 M, 69.7 -> 66.9 ms at 10 M)
@@ -884,7 +885,8 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
                    const std::function<int()>* after_first_shot = nullptr, const std::function<int(const RState&)>* mid_loop = nullptr) {
     const int np = c->npad, K = c->K;
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
-                       (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p);
+                       (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, c->eval_src);
+    c->eval_src = 0;
     c->ctr.kernel_launches++;
     std::vector<Span> tally_spans, resolve_spans;
     RState st{};
@@ -943,11 +945,9 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         c->stat_iters += st.iter;
         c->stat_events += n_new_events;
     }
-    if (st.iter & 1) {
-        // the per-member exhaustion marks persist across runs; the next run reads half 0
-        HIPCHK(c, hipMemcpyAsync(c->d_evalround.p, c->d_evalround.p + np, np * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_evalpos.p, c->d_evalpos.p + np, np * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-    }
+    // the per-member exhaustion marks persist across runs; the next run reads half 0: its k_loop_init moves them there
+    // (two small device copies here sat in the gap between two sub-batches' loops)
+    c->eval_src = st.iter & 1;
     c->R = st.max_round + 1;
     if (c->unit_stake && c->tally_impl == 2) {   // the tree search counts the tallies it really evaluated (per member, read back with the state)
         const int32_t* tc = reinterpret_cast<const int32_t*>(c->h_rb + ((unsigned char*)c->d_treecnt - c->d_rb));
@@ -2986,21 +2986,35 @@ int sw_rewind(sw_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream_cs));   // (calls return without a host synchronisation)
     HIPCHK(c, hipStreamSynchronize(c->stream_aux));
     const size_t rows = (size_t)c->Rcap * c->npad;
-    CHK(fill_i32(c, c->d_lo.p, rows, SW_INF));
-    CHK(fill_i32(c, c->d_lopos.p, rows, 0));
-    CHK(fill_i32(c, c->d_wit.p, rows, -1));
-    CHK(fill_i32(c, c->d_dec_call.p, rows, -1));
-    CHK(fill_i32(c, c->d_dec_by.p, rows, -1));
     c->fame_calls.clear();
     c->votes_partial = false;
+    c->eval_src = 0;
     std::fill(c->cons_call.begin(), c->cons_call.end(), -1);
-    HIPCHK(c, hipMemsetAsync(c->d_fam.p, 0xff, rows, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_cons.p, 0, c->Rcap, c->stream));
-    CHK(fill_i32(c, c->d_evalround.p, 2 * c->npad, -1));
-    CHK(fill_i32(c, c->d_evalpos.p, 2 * c->npad, 0));
-    if (c->N) HIPCHK(c, hipMemsetAsync(c->d_round.p, 0xff, (size_t)c->N * sizeof(int32_t), c->stream));
-    CHK(fill_i32(c, c->d_front.p, c->npad, -1));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   // every table back to its initial value, one launch (byte tables as 32-bit words: their allocations are padded to 256 B)
+        RewindJob J{};
+        int nj = 0;
+        auto job = [&](void* p_, size_t words, int v) { if (p_ && words) { J.p[nj] = (int*)p_; J.n[nj] = words; J.v[nj] = v; ++nj; } };
+        job(c->d_lo.p, rows, SW_INF);
+        job(c->d_lopos.p, rows, 0);
+        job(c->d_wit.p, rows, -1);
+        job(c->d_dec_call.p, rows, -1);
+        job(c->d_dec_by.p, rows, -1);
+        job(c->d_evalround.p, 2 * (size_t)c->npad, -1);
+        job(c->d_evalpos.p, 2 * (size_t)c->npad, 0);
+        job(c->d_front.p, c->npad, -1);
+        job(c->d_round.p, (size_t)c->N, -1);
+        if (rows % 4 == 0) job(c->d_fam.p, rows / 4, -1);
+        else HIPCHK(c, hipMemsetAsync(c->d_fam.p, 0xff, rows, c->stream));
+        if (c->Rcap % 4 == 0) job(c->d_cons.p, (size_t)c->Rcap / 4, 0);
+        else HIPCHK(c, hipMemsetAsync(c->d_cons.p, 0, c->Rcap, c->stream));
+        size_t longest = 1;
+        for (int i = 0; i < nj; ++i) longest = std::max<size_t>(longest, J.n[i]);
+        if (nj) {
+            hipLaunchKernelGGL(k_rewind_fill, dim3((unsigned)std::min<size_t>((longest + 1023) / 1024, 1024), nj), dim3(256), 0, c->stream, J);
+            c->ctr.kernel_launches++;
+            HIPCHK(c, hipGetLastError());
+        }
+    }
     std::fill(c->front.begin(), c->front.end(), -1);
     std::fill(c->divided_cnt.begin(), c->divided_cnt.end(), 0);
     if (c->vm.active && c->vm.lo > 0) {
