@@ -11,6 +11,8 @@ import json; d=json.load(open('$O/bench_default.json')); print(d['value'], d['ms
 for k in d['roofline']['kernels']: print(k['kernel'], k['launches'], k['avg_launch_us'], k['total_ms'], k['frac'], k['hbm_bytes_per_launch_pmc'])"
 SW_COMMIT=$(cat .commit_id 2>/dev/null || echo unknown) timeout 600 bash profiles/run_profiles.sh $1 > $O/prof.log 2>&1
 head -14 gpurun_out/prof_$1/kernel_stats.txt; cat gpurun_out/prof_$1/loop_timeline.txt | head -6
+python profiles/pass_timeline.py gpurun_out/prof_$1/kt_results.db 9 > $O/pass_timeline_256x1M.txt 2>&1; tail -1 $O/pass_timeline_256x1M.txt
+timeout 120 python profiles/order_laps.py 256 1000000 > $O/order_laps_256x1M.txt 2>&1; tail -3 $O/order_laps_256x1M.txt
 SW_DEBUG_CLOCKS=1 SW_PIPE=1 timeout 120 python profiles/loop_phases.py 256 1000000 > $O/loop_phases_256x1M.txt 2>&1
 SW_DEBUG_CLOCKS=2 timeout 120 python profiles/resolve_time.py 256 1000000 > $O/resolve_time_256x1M.txt 2>&1
 timeout 120 python profiles/block_ends.py 256 1000000 > $O/workgroup_end_times_256x1M.txt 2>&1
