@@ -66,3 +66,20 @@ for name, b in (("member 0, slot K/2", T), ("last member, slot K/2", Tl)):
     if okk.any():
         q("end - entry", t[i1[okk], b + 5] - t[i1[okk], b])
         q("end -> next resolve entry", t[i1[okk] + 1, A] - t[i1[okk], b + 5])
+# ---- which iterations are the slow ones?  (period against the band built in that iteration, the kernel's own length and
+# the gaps on either side of the tally)
+per = (t[idx + 1, A] - t[idx, A]) / 100.0
+band = t[idx, A + 7]
+res_len = (t[idx, 6] - t[idx, 0]) / 100.0
+slow = per > np.percentile(per, 50) * 1.25
+print(" slow iterations (period > 1.25 x median): %d of %d, mean period %.1f us (the others %.1f us)" % (slow.sum(), len(per), per[slow].mean() if slow.any() else 0, per[~slow].mean()))
+if slow.any():
+    print("   band events built: slow %.0f, others %.0f;  resolve kernel entry -> end: slow %.2f us, others %.2f us" % (band[slow].mean(), band[~slow].mean(), res_len[slow].mean(), res_len[~slow].mean()))
+    okT = t[idx, T + 5] > 0
+    for lab, m in (("slow", slow & okT), ("others", ~slow & okT)):
+        if m.any():
+            i2 = idx[m]
+            print("   %-6s resolve end -> tally wave entry %.2f us, tally wave %.2f us, its end -> next resolve entry %.2f us" % (
+                lab, ((t[i2, T] - t[i2, 6]) / 100.0).mean(), ((t[i2, T + 5] - t[i2, T]) / 100.0).mean(), ((t[i2 + 1, A] - t[i2, T + 5]) / 100.0).mean()))
+    print("   iteration index of the slow ones (mod 24):", np.bincount(idx[slow] % 24, minlength=24).tolist())
+    print("   first 40 slow iteration indices:", idx[slow][:40].tolist())

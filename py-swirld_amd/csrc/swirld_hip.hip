@@ -214,8 +214,10 @@ struct sw_ctx {
     // round-loop graph
     struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; int K, tally_impl, BATCH, MCAP; };
     bool use_graph = true;
-    hipGraph_t loop_graph[3] = {nullptr, nullptr, nullptr};
-    hipGraphExec_t loop_exec[3] = {nullptr, nullptr, nullptr};
+    hipGraph_t loop_graph[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t loop_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+    int graph_big = 64;    // SW_GRAPH_BIG: iterations of the largest replayable graph (0 = none beyond 24).  Every graph boundary costs
+                           // the loop ≈ 8 us (profiles/r04y_loop_phases_256x1M.txt: iterations 23, 47, 71, ... are the slow ones)
     GraphKey loop_key{};
     int64_t stat_iters = 0, stat_events = 0;  // iterations-per-event history (first-shot sizing)
 
@@ -837,10 +839,10 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
     c->ctr.kernel_launches += 2;
 }
 
-// the loop body as replayable hipGraphs of 24 / 8 / 2 iterations (2 kernel nodes each); the
+// the loop body as replayable hipGraphs of [SW_GRAPH_BIG /] 24 / 8 / 2 iterations (2 kernel nodes each); the
 // kernel arguments are frozen at capture, so the graphs are rebuilt when any of them changes.
 // Iteration counts are even because the loop state is double-buffered by iteration parity.
-constexpr int kGraphSizes[3] = {24, 8, 2};
+constexpr int kGraphSizesBase[4] = {0, 24, 8, 2};
 
 template <int NW>
 int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, std::vector<Span>* resolve_spans = nullptr) {
@@ -855,14 +857,16 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
     key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
-        for (int g = 0; g < 3; ++g) {
+        for (int g = 0; g < 4; ++g) {
             if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
             if (c->loop_graph[g]) { (void)hipGraphDestroy(c->loop_graph[g]); c->loop_graph[g] = nullptr; }
         }
         c->loop_key = key;
     }
     int left = n_iters;
-    for (int g = 0; g < 3; ++g) {
+    const int kGraphSizes[4] = {c->graph_big, kGraphSizesBase[1], kGraphSizesBase[2], kGraphSizesBase[3]};
+    for (int g = 0; g < 4; ++g) {
+        if (kGraphSizes[g] <= 0) continue;
         while (left >= kGraphSizes[g]) {
             if (!c->loop_exec[g]) {
                 HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1900,6 +1904,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     c->MCAP = std::max(c->MCAP, c->NEARCAP);
     knob("SW_BATCH", 1, 4096, &c->BATCH);
     knob("SW_GRAPH", 0, 1, &graph);
+    knob("SW_GRAPH_BIG", 0, 512, &c->graph_big);
+    c->graph_big &= ~1;
     c->use_graph = graph != 0;
     // 1024-thread workgroups (1024 members): one per CU is resident, 512 would run as two shifts (profiles/r04n_*: 41.4 -> 40.1 ms at 1024 x 2 M)
     if (c->npad >= 1024) c->band_blocks = 256;
@@ -2086,7 +2092,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_rbnd); dfree(c->d_rcuts);
     if (c->d_rprov) (void)hipFree(c->d_rprov);
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < 4; ++g) {
         if (c->loop_exec[g]) (void)hipGraphExecDestroy(c->loop_exec[g]);
         if (c->loop_graph[g]) (void)hipGraphDestroy(c->loop_graph[g]);
     }
