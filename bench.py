@@ -385,7 +385,9 @@ def main():
     hbm_pmc = None
     if traffic:
         per_pass = {cs_name: tm["cansee_launches"], "k_resolve_band": cd["round_iterations"], tally_name: cd["round_iterations"],
-                    "k_elections": 1, "k_voter_masks_bits": tm["cansee_launches"], "k_finalize_events": tm["cansee_launches"]}
+                    "k_elections": 1, "k_voter_masks_bits": tm["cansee_launches"],
+                    # (round numbers / sees-masks: written by the band pass of k_resolve_band, then one check + one launch for the listed leftovers per sub-batch)
+                    "k_finalize_check": tm["cansee_launches"], "k_finalize_listed": tm["cansee_launches"], "k_finalize_events": 0}
         if all(traffic.get(k) is not None for k in (cs_name, "k_resolve_band", tally_name)):
             hbm_pmc = int(sum(traffic.get(k, 0) * v for k, v in per_pass.items()))
     roofline = {

@@ -232,6 +232,8 @@ typedef struct sw_counters {
     int64_t chunk_provisional;   /* entries a chunk could not know (ancestor older than its halo)        */
     int64_t chunk_repaired;      /* ... of which changed by the repair kernel                            */
     int64_t chunk_resweeps;      /* chunks swept a second time from final rows (too many to repair)      */
+    /* ABI v5 */
+    int64_t finalize_from_rows;  /* events whose round / sees-mask no band pass of their own round wrote: recomputed from their rows */
 } sw_counters;
 int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 /* The same for a caller built against another version of this header: copies min(out_bytes, sizeof(sw_counters))

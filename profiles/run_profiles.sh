@@ -21,7 +21,7 @@ python profiles/loop_timeline.py "$DB" > $OUT/loop_timeline.txt 2>> $OUT/kt_run.
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python bench.py $PMCARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python bench.py $PMCARGS > $OUT/write.log 2>&1
 python profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json "$COMMIT" "bench.py $PMCARGS" \
-    k_cansee_chunks k_cansee_fixup k_cansee_flow k_cansee_stream k_resolve_band k_tally_bits k_tally_tree k_elections k_voter_masks_bits k_finalize_events > $OUT/traffic.log 2>&1
+    k_cansee_chunks k_cansee_fixup k_cansee_flow k_cansee_stream k_resolve_band k_tally_bits k_tally_tree k_elections k_voter_masks_bits k_finalize_events k_finalize_check k_finalize_listed > $OUT/traffic.log 2>&1
 # 3. wave / wait / cache counters
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS \
     --output-format csv -d $OUT/pmc1 -o p1 -- python bench.py $PMCARGS > $OUT/pmc1.log 2>&1

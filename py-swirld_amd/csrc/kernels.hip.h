@@ -33,6 +33,8 @@ struct RState {
     u64 evals;      // tallies evaluated (live candidates)
     u64 far_hops;   // hop masks computed on the fly (outside the band)
     u64 band_events;  // band events whose threshold mask was (re)built (work of k_resolve_band's step 2)
+    int fin_from;     // first event of THIS run's sub-batch: band events from here on get their round and sees-mask from the band pass
+    int pad_;
 };
 
 struct FameCounters {
@@ -990,7 +992,7 @@ __device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v));
 // Start of a round-loop run: the loop state and the per-member buffers in ONE launch (a small
 // call would otherwise pay five separate copies / fills, ~10 us each).
 __global__ void __launch_bounds__(1024)
-k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len, int eval_src) {
+k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len, int eval_src, int fin_from) {
     // chain lengths visible to this run = the sub-batch's row of the cut table (already on the device)
     for (int i = threadIdx.x; i < npad; i += blockDim.x) { chain_len[i] = visible_len[i]; B.treecnt[i] = 0; }
     if (eval_src)   // the previous run ended on an odd iteration: its exhaustion marks are in half 1, this run reads half 0
@@ -1000,6 +1002,7 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
         t.r = r_start;
         t.N = N;
         t.ncap = ncap;
+        t.fin_from = fin_from;
         B.st[0] = t;
     }
     for (int i = threadIdx.x; i < 2 * npad; i += blockDim.x) {
@@ -1021,7 +1024,8 @@ __global__ void __launch_bounds__(1024)
 k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
-               const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb) {
+               const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb,
+               int* __restrict__ round_out, u64* __restrict__ S_out) {
     __shared__ int s_red[2][4][16];  // [parity][quantity][wave]: per-wave partial results
     __shared__ int s_thr[1024];
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
@@ -1052,6 +1056,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     const int iter = si->iter;
     const int N = si->N;
     const int s_mlo = si->mlo, s_mhi = si->mhi, s_ncap = si->ncap;
+    const int fin_from = si->fin_from;
     const int cs = member ? chain_start[c] : 0;
     const int clen = member ? chain_len[c] : 0;  // events of member c visible to this run
     int un = member ? B.unres[in + c] : 0;
@@ -1402,7 +1407,14 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         // cost a dependent load, an unused mask costs 1 KB of row traffic)
         const int base = g * 8;
         const int kk = base + (lane & 7);
-        u64 vm = __ballot(lane < 8 && kk < mhi && kk >= mask_from);
+        const bool mine = lane < 8 && kk < mhi && kk >= mask_from;
+        u64 vm = __ballot(mine);
+        // FINALIZE FROM THE BAND (round 4): a band event of this run's sub-batch that lies at or after its
+        // creator's round-r witness has round >= r, and its mask against lo[r] — the ballots below — is its sees-mask if its round
+        // IS r.  The pass of the event's true round is the last one to write it (rounds only go up), so after the loop
+        // round[e] / S[e] are final for every event a band of its own round covered; k_finalize_check finds the others.
+        const int fin_thr = mine ? s_thr[cr[kk]] : SW_INF;   // lo[r][creator]: INF when the creator has no round-r witness
+        const u64 fin_m = __ballot(mine && kk >= fin_thr && kk >= fin_from);
         constexpr int RIF = NW <= 4 ? 8 : 4;  // rows in flight per wave (one memory round trip per pass)
         while (vm) {
             int ks[RIF];
@@ -1420,10 +1432,16 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
 #pragma unroll
             for (int u = 0; u < RIF; ++u)
                 if (ks[u] >= 0) {
+                    u64 word = 0;   // lane j < NW keeps mask word j: the NW words of an event leave in ONE store instruction
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
                         const u64 bm = __ballot(v[u][j] >= t_[j]);
-                        if (lane == 0) Mb[(size_t)(ks[u] - mlo) * NW + j] = bm;
+                        word = lane == j ? bm : word;
+                    }
+                    if (lane < NW) Mb[(size_t)(ks[u] - mlo) * NW + lane] = word;
+                    if ((fin_m >> (ks[u] - base)) & 1ull) {
+                        if (lane < NW) S_out[(size_t)ks[u] * NW + lane] = word;
+                        if (lane == NW) round_out[ks[u]] = r;
                     }
                 }
         }
@@ -2109,8 +2127,38 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
 
 // ---------------------------------------------------------------------------------
 // Finalize: round numbers (swirld.py:217-219) and sees-masks for the events of the batch.
-// round[e] = max r with lo[r][creator(e)] <= e  (binary search of one column of lo).
+// round[e] = max r with lo[r][creator(e)] <= e  (search of one column of lo).
+// Since round 4 the round loop's band pass writes both for every band event it covers in the pass of the event's own round
+// (k_resolve_band): what is left is a CHECK — one thread per event, a binary search of its creator's lo column (L2-resident),
+// no row read: round[e] equal to the searched round means the pass of that round wrote S[e] as well — and the recomputation
+// from the row of the few events no band of their own round covered (band caps, the end of a chain), listed by the check.
 // ---------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void finalize_one(const int e, const int lane, const int* __restrict__ L, const int* __restrict__ cr,
+                                             const int* __restrict__ lo, const int R, int* round, u64* S, const int npad) {
+    const int c = cr[e];
+    // 64-ary search of the (non-decreasing) column lo[.][c]: 2 dependent probes for R <= 4096
+    int a = 0, len = R;  // the answer lies in [a, a + len); lo[0][c] <= e always (chain start)
+    while (len > 1) {
+        const int stride = (len + 63) >> 6;
+        const int row = a + lane * stride;
+        const bool ok = row < a + len && lo[(size_t)row * npad + c] <= e;
+        const u64 bal = __ballot(ok);
+        const int hi = 63 - __clzll((long long)bal);
+        const int end = a + len;
+        a += hi * stride;
+        len = end - a < stride ? end - a : stride;
+    }
+    if (lane == 0) round[e] = a;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int v = L[(size_t)e * npad + j * 64 + lane];
+        const u64 bm = __ballot(v >= lo[(size_t)a * npad + j * 64 + lane]);
+        if (lane == 0) S[(size_t)e * NW + j] = bm;
+    }
+}
+
+// every event of [first, first + K) from its row (SW_FIN_BAND=0, and callers that have no band pass behind them)
 template <int NW>
 __global__ void __launch_bounds__(256)
 k_finalize_events(const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ lo,
@@ -2118,29 +2166,37 @@ k_finalize_events(const int* __restrict__ L, const int* __restrict__ cr, const i
     const int lane = lane_id();
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int i = wave; i < K; i += nwaves) {
-        const int e = first + i;
-        const int c = cr[e];
-        // 64-ary search of the (non-decreasing) column lo[.][c]: 2 dependent probes for R <= 4096
-        int a = 0, len = R;  // the answer lies in [a, a + len); lo[0][c] <= e always (chain start)
-        while (len > 1) {
-            const int stride = (len + 63) >> 6;
-            const int row = a + lane * stride;
-            const bool ok = row < a + len && lo[(size_t)row * npad + c] <= e;
-            const u64 bal = __ballot(ok);
-            const int hi = 63 - __clzll((long long)bal);
-            const int end = a + len;
-            a += hi * stride;
-            len = end - a < stride ? end - a : stride;
-        }
-        if (lane == 0) round[e] = a;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int v = L[(size_t)e * npad + j * 64 + lane];
-            const u64 bm = __ballot(v >= lo[(size_t)a * npad + j * 64 + lane]);
-            if (lane == 0) S[(size_t)e * NW + j] = bm;
-        }
+    for (int i = wave; i < K; i += nwaves) finalize_one<NW>(first + i, lane, L, cr, lo, R, round, S, npad);
+}
+
+// the check: events whose round[] is not the round their creator's lo column gives go on the list.  fin[0] = length of the
+// list (zeroed by the host before the launch), fin[1] = running total (read by sw_get_counters)
+__global__ void __launch_bounds__(256)
+k_finalize_check(const int* __restrict__ cr, const int* __restrict__ lo, int R, int first, int K,
+                 const int* __restrict__ round, int npad, int* __restrict__ list, unsigned* __restrict__ fin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int e = first + i;
+    const int c = cr[e];
+    int a = 0, b = R;   // the round lies in [a, b): lo[a][c] <= e (lo[0][c] = the chain start), lo[b][c] > e or b = R
+    while (b - a > 1) {
+        const int mid = (a + b) >> 1;
+        if (lo[(size_t)mid * npad + c] <= e) a = mid; else b = mid;
     }
+    if (round[e] != a) list[atomicAdd(&fin[0], 1u)] = e;
+}
+
+// ... and the listed events from their rows, one wave per event
+template <int NW>
+__global__ void __launch_bounds__(256)
+k_finalize_listed(const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ lo, int R,
+                  const int* __restrict__ list, unsigned* __restrict__ fin, int* round, u64* S, int npad) {
+    const int lane = lane_id();
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int cnt = (int)fin[0];
+    for (int i = wave; i < cnt; i += nwaves) finalize_one<NW>(list[i], lane, L, cr, lo, R, round, S, npad);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(fin + 2), (unsigned long long)cnt);
 }
 
 // Witness table (swirld.py:197, 221-222): member c has a witness in round r iff its first

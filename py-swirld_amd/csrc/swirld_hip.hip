@@ -104,6 +104,8 @@ struct sw_ctx {
     DBuf<unsigned char> d_coin, d_sig;
     DBuf<double> d_t;
     DBuf<u64> d_S;
+    DBuf<int32_t> d_finlist;   // events k_finalize_check found without a round from the band pass (one entry per event at most)
+    unsigned* d_fin = nullptr; // [0] length of that list for the launch in flight, [2..3] running total (u64)
     DBuf<int32_t> d_chain_start;  // npad: offset of each member's segment in the chain pool
     DBuf<int32_t> d_chain_cnt;    // npad: events per member (segments have slack: geometric growth)
     DBuf<int4> d_cdesc;           // pool-indexed chain descriptors of the dataflow can_see sweep (same indexing as chain_ev)
@@ -208,11 +210,13 @@ struct sw_ctx {
     int band_blocks = 512; // workgroups of the resolve+band kernel
     int fin_blocks = 1024; // SW_FIN_BLOCKS: workgroups of a k_finalize_events launch that runs beside a round loop (profiles/r04q_*: 8192 of them
                            // slow the loop's gathers down; 1024 with the early finalize below: 7.30 -> 7.16 ms per pass at 256 x 1 M, 69.7 -> 66.9 ms at 10 M)
-    int mid_pct = 88;      // SW_MID_PCT: where the last sub-batch's round loop is interrupted once for the early finalize (0 = never)
+    int mid_pct = 0;       // SW_MID_PCT: where the last sub-batch's round loop is interrupted once for an early finalize (0 = never: with
+                           // SW_FIN_BAND=1 there is nothing left to hide; 88 was the default of the row-reading finalize)
+    int fin_band = 1;      // SW_FIN_BAND: round[] and the sees-masks come from the round loop's band pass, the finalize launch only checks (1) / every event from its row (0)
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
     // round-loop graph
-    struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; int K, tally_impl, BATCH, MCAP; };
+    struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; void* S; void* round; int K, tally_impl, BATCH, MCAP; };
     bool use_graph = true;
     hipGraph_t loop_graph[4] = {nullptr, nullptr, nullptr, nullptr};
     hipGraphExec_t loop_exec[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -433,6 +437,7 @@ int ensure_events(sw_ctx* c, int64_t need) {
     CHK(dgrow(c, c->d_ht, nc, keep));
     CHK(dgrow(c, c->d_seq, nc, keep));
     CHK(dgrow(c, c->d_round, nc, keep));
+    CHK(dgrow(c, c->d_finlist, nc, 0));
     CHK(dgrow(c, c->d_coin, nc, keep));
     CHK(dgrow(c, c->d_t, nc, keep));
     CHK(dgrow(c, c->d_sig, (size_t)nc * 64, keep * 64));
@@ -813,7 +818,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
     hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW);
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p);
     if (resolve_spans) { span_end(c, sr); resolve_spans->push_back(sr); }
     Span s{};
     if (tally_spans) s = span_begin(c);
@@ -855,6 +860,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     memset(&key, 0, sizeof key);
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
+    key.S = (void*)c->d_S.p; key.round = (void*)c->d_round.p;
     key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
         for (int g = 0; g < 4; ++g) {
@@ -884,12 +890,40 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     return SW_OK;
 }
 
+// round numbers and sees-masks of the events [first, first + K) on `ax`, table rows 0 .. R-1 final: with the band pass
+// writing them (SW_FIN_BAND=1) a check of one thread per event + the listed leftovers from their rows, else every event
+// from its row.  `blocks` = workgroups of the row-reading launch.
+template <int NW>
+int launch_finalize(sw_ctx* c, hipStream_t ax, int64_t first, int64_t K, int R, int blocks) {
+    const int np = c->npad;
+    if (K <= 0) return SW_OK;
+    if (!c->fin_band) {
+        hipLaunchKernelGGL(k_finalize_events<NW>, dim3((unsigned)std::min<int64_t>((K + 3) / 4, blocks)), dim3(256), 0, ax, (const int*)c->d_L.p,
+                           (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)first, (int)K, c->d_round.p, c->d_S.p, np);
+        c->ctr.kernel_launches++;
+        return SW_OK;
+    }
+    if (!c->d_fin) {
+        HIPCHK(c, hipMalloc((void**)&c->d_fin, 16));
+        HIPCHK(c, hipMemset(c->d_fin, 0, 16));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_fin, 0, sizeof(unsigned), ax));
+    hipLaunchKernelGGL(k_finalize_check, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ax, (const int*)c->d_cr.p, (const int*)c->d_lo.p, R,
+                       (int)first, (int)K, (const int*)c->d_round.p, np, c->d_finlist.p, c->d_fin);
+    hipLaunchKernelGGL(k_finalize_listed<NW>, dim3((unsigned)std::min<int64_t>((K + 3) / 4, std::min(blocks, 1024))), dim3(256), 0, ax, (const int*)c->d_L.p,
+                       (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (const int*)c->d_finlist.p, c->d_fin, c->d_round.p, c->d_S.p, np);
+    c->ctr.kernel_launches += 2;
+    return SW_OK;
+}
+
 template <int NW>
 int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, const int32_t* visible_len, float* tally_ms_out, int* tally_launches_out,
-                   const std::function<int()>* after_first_shot = nullptr, const std::function<int(const RState&)>* mid_loop = nullptr) {
+                   const std::function<int()>* after_first_shot = nullptr, const std::function<int(const RState&)>* mid_loop = nullptr,
+                   int64_t fin_from = 0x7fffffff) {
     const int np = c->npad, K = c->K;
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
-                       (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, c->eval_src);
+                       (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, c->eval_src,
+                       (int)std::min<int64_t>(fin_from, 0x7fffffff));
     c->eval_src = 0;
     c->ctr.kernel_launches++;
     std::vector<Span> tally_spans, resolve_spans;
@@ -1278,15 +1312,13 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             // events below the band of round st.r: round <= st.r - 1, rows 0 .. st.r of the table are committed and final
             CHK(ensure_rounds(c, st.r + 2));
             const int64_t k1 = upto - fin_from;
-            hipLaunchKernelGGL(k_finalize_events<NW>, dim3((unsigned)std::min<int64_t>((k1 + 3) / 4, c->fin_blocks)), dim3(256), 0, c->stream_aux, (const int*)c->d_L.p,
-                               (const int*)c->d_cr.p, (const int*)c->d_lo.p, st.r + 1, (int)fin_from, (int)k1, c->d_round.p, c->d_S.p, np);
-            c->ctr.kernel_launches++;
+            CHK(launch_finalize<NW>(c, c->stream_aux, fin_from, k1, st.r + 1, c->fin_blocks));
             fin_from = upto;
             return SW_OK;
         };
         const bool split_fin = i == S - 1 && cut[i + 1] - cut[i] >= 65536;
         CHK(run_round_loop<NW>(c, r_start, limit, cut[i + 1] - cut[i], c->d_bounds.p + (size_t)(i + 1) * np, &tally_ms, &tally_launches, &pending_aux,
-                               split_fin ? &early_fin : nullptr));
+                               split_fin ? &early_fin : nullptr, c->fin_band ? cut[i] : 0x7fffffff));
         CHK(pending_aux());   // (a loop that returned before its first shot — never — would have left it undone)
         if (dbg_t) {
             const auto dbg_t2 = std::chrono::steady_clock::now();
@@ -1339,13 +1371,12 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                 // (a finalize that runs beside the next round loop is throttled: fewer workgroups, less pressure on the loop's gathers;
                 // the last one has nothing to hide behind and takes the whole GPU)
                 const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, i_ == S_ - 1 ? 8192 : c->fin_blocks);
-                hipLaunchKernelGGL(k_finalize_events<NW>, dim3(blocks), dim3(256), 0, ax, (const int*)c->d_L.p,
-                                   (const int*)c->d_cr.p, (const int*)c->d_lo.p, R, (int)a0, (int)k0, c->d_round.p, c->d_S.p, np);
+                CHK(launch_finalize<NW>(c, ax, a0, k0, R, blocks));
                 const int total = (R - rs_) * np;
                 if (total > 0)
                     hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, ax,
                                        (const int*)c->d_lo.p, R, rs_, np, c->d_wit.p);
-                c->ctr.kernel_launches += 2;
+                c->ctr.kernel_launches += 1;
                 return launch_voter_masks<NW>(c, rs_, R, ax);
             };
         }
@@ -1829,7 +1860,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
 // ====================================================================================
 extern "C" {
 
-int sw_version(void) { return 4; }
+int sw_version(void) { return 5; }
 
 const char* sw_last_error(const sw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1912,6 +1943,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     knob("SW_BAND_BLOCKS", 1, 4096, &c->band_blocks);
     knob("SW_TALLY_PF", 0, 1, &c->tally_pf);
     knob("SW_MID_PCT", 0, 99, &c->mid_pct);
+    knob("SW_FIN_BAND", 0, 1, &c->fin_band);
     knob("SW_FIN_BLOCKS", 64, 8192, &c->fin_blocks);
     knob("SW_PIPE", 1, 64, &c->pipe);
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
@@ -2074,7 +2106,8 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->x_fam_ev); dfree(c->x_votes); dfree(c->x_tbd); dfree(c->x_sm); dfree(c->x_done); dfree(c->x_visited); dfree(c->x_sflag);
     dfree(c->x_white); dfree(c->x_times); dfree(c->x_tsort); dfree(c->x_items_ts); dfree(c->x_hdr);
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
-    dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S);
+    dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S); dfree(c->d_finlist);
+    if (c->d_fin) (void)hipFree(c->d_fin);
     dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
@@ -3347,14 +3380,27 @@ int sw_get_transactions(sw_ctx* c, int64_t first, int64_t K, int32_t* out) {
     return SW_OK;
 }
 
+// (one counter lives on the device: the events the finalize check sent back to their rows)
+static int refresh_device_counters(sw_ctx* c) {
+    if (!c->d_fin) return SW_OK;
+    unsigned long long tot = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+    HIPCHK(c, hipMemcpy(&tot, c->d_fin + 2, sizeof tot, hipMemcpyDeviceToHost));
+    c->ctr.finalize_from_rows = (int64_t)tot;
+    return SW_OK;
+}
+
 int sw_get_counters(sw_ctx* c, sw_counters* out) {
     if (!c || !out) return SW_EINVAL;
+    CHK(refresh_device_counters(c));
     *out = c->ctr;
     return SW_OK;
 }
 
 int sw_get_counters_sized(sw_ctx* c, void* out, size_t out_bytes) {
     if (!c || !out) return SW_EINVAL;
+    CHK(refresh_device_counters(c));
     memcpy(out, &c->ctr, std::min(out_bytes, sizeof(sw_counters)));
     return SW_OK;
 }

@@ -50,10 +50,11 @@ def hip_run(pkg, run, monkeypatch=None, env=None):
 def test_config3_one_million_events_bit_exact(pkg, oracle_pool, monkeypatch, gallop):
     run = oracle_pool.get("c3_256x1M")
     o = run.oracle
-    # (the gallop variant also moves the early finalize of the last sub-batch — events below the band of the round in
-    # progress are finalized beside the rest of its loop — to the middle of that loop, with the unthrottled launch shape)
+    # (the default run takes round[] and the sees-masks from the band pass; the gallop variant finalizes every event from its
+    # row, with the early finalize of the last sub-batch — events below the band of the round in progress, beside the rest of
+    # its loop — in the middle of that loop and the unthrottled launch shape)
     h, ncs = hip_run(pkg, run, monkeypatch, {"SW_GALLOP": gallop} if gallop == "0" else
-                     {"SW_GALLOP": gallop, "SW_MID_PCT": "50", "SW_FIN_BLOCKS": "8192", "SW_ELECT_CG": "64"})
+                     {"SW_GALLOP": gallop, "SW_FIN_BAND": "0", "SW_MID_PCT": "50", "SW_FIN_BLOCKS": "8192", "SW_ELECT_CG": "64"})
     assert ncs == run.new_c
     if gallop == "0":
         compare_state(h, o, run.N)

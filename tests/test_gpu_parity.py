@@ -232,6 +232,7 @@ def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
     members, band doubling, and (cap == limit) forced tallies with on-the-fly hop masks."""
     cases = [(48, 15000, 60, 2, 0.2, 0.03), (24, 9000, 61, 2, 0.3, 0.004), (16, 6000, 62, 1, 0.01, 0)]
     oracles = {}
+    from_rows = 0
     for k, band, band_max in [("4", "64", None), ("4", "100000", None), ("32", "128", None),
                               ("8", "64", "64"), ("16", "256", "512"),
                               ("31", "4096", None), ("63", "256", None), ("1", "4096", None)]:  # candidate-table widths
@@ -250,7 +251,28 @@ def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
             h, ncs_h = hip_run(pkg, n, stream)
             assert ncs_h == ncs_o
             assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+            if band == "64":   # a band capped at 64 events does not cover every event in the pass of its own round:
+                from_rows += h.counters()["finalize_from_rows"]   # the finalize check sends those back to their rows
             h.close()
+    assert from_rows > 0
+
+
+@pytest.mark.parametrize("fin_band", ["0", "1"])
+def test_round_numbers_from_the_band_pass_or_from_the_rows(pkg, monkeypatch, fin_band):
+    """round[] and the sees-masks (swirld.py:217-219; the voters' hop masks of decide_fame) written by the round loop's band
+    pass and checked afterwards (SW_FIN_BAND=1, the default) against every event finalized from its row (0): batch and
+    incremental schedules, slow members, two cliques, stale other-parents."""
+    monkeypatch.setenv("SW_FIN_BAND", fin_band)
+    for n, N, seed, mode, p0, p1, chunk in [(130, 14000, 175, 0, 0, 0, None), (256, 30000, 176, 2, 0.2, 0.05, 7000),
+                                            (100, 9000, 177, 1, 0.02, 0, 1500), (200, 20000, 178, 3, 0.6, 0, 333), (40, 8000, 179, 2, 0.5, 0.01, 1)]:
+        stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+        o, ncs_o = oracle_run(n, stream, chunk=chunk)
+        h, ncs_h = hip_run(pkg, n, stream, chunk=chunk)
+        assert ncs_h == ncs_o
+        assert_state_equal(h, o.round, o.can_see, o.witnesses(), o.famous_by_event, o.consensus())
+        if fin_band == "0":
+            assert h.counters()["finalize_from_rows"] == 0
+        h.close()
 
 
 @pytest.mark.parametrize("cansee,tally,ring_h", [("2", "1", None), ("2", "1", "1"), ("2", "0", "4"), ("3", "1", "2"), ("3", "0", None),

@@ -33,6 +33,9 @@ def test_random_shapes(pkg, monkeypatch, seed):
         monkeypatch.setenv("SW_CHUNK_CFG", str(int(rng.choice([0, 1, 2]))))
     cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 9000 + seed, mode, p0, p1)
     t = t + rng.integers(0, 3, N) * 0.5
+    # (drawn after everything else, so that the shapes of the earlier rounds' sweeps stay what they were) round numbers and
+    # sees-masks from the band pass + check (default) or every event from its row
+    monkeypatch.setenv("SW_FIN_BAND", str(int(np.random.default_rng(8000 + seed).choice([0, 1, 1]))))
     stake = None
     if n >= 8 and rng.random() < 0.2:  # near-unit weighted stakes (the only weighted kind that progresses)
         stake = np.ones(n, np.uint64)
