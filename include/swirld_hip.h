@@ -234,6 +234,7 @@ typedef struct sw_counters {
     int64_t chunk_resweeps;      /* chunks swept a second time from final rows (too many to repair)      */
     /* ABI v5 */
     int64_t finalize_from_rows;  /* events whose round / sees-mask no band pass of their own round wrote: recomputed from their rows */
+    int64_t order_rounds_host_sorted; /* find_order: rounds the host sorted (a tie on timestamp and the first 8 key bytes)   */
 } sw_counters;
 int sw_get_counters(sw_ctx* ctx, sw_counters* out);
 /* The same for a caller built against another version of this header: copies min(out_bytes, sizeof(sw_counters))

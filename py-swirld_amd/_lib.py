@@ -23,7 +23,7 @@ class Counters(C.Structure):
     _fields_ = [(k, C.c_int64) for k in (
         "events_divided", "rounds", "tally_evals", "round_iterations", "voter_evals",
         "majority_evals", "levels", "kernel_launches", "far_hops", "band_events", "coin_votes", "coin_flips",
-        "chunk_sweeps", "chunk_provisional", "chunk_repaired", "chunk_resweeps", "finalize_from_rows")]
+        "chunk_sweeps", "chunk_provisional", "chunk_repaired", "chunk_resweeps", "finalize_from_rows", "order_rounds_host_sorted")]
 
 
 class Timings(C.Structure):

@@ -3033,6 +3033,69 @@ k_order_sort(const int* __restrict__ acc_ev, const long long* __restrict__ acc_o
     if (__syncthreads_or(tie) && tid == 0) host_flag[ri] = 1;
 }
 
+// ... and the rounds with more than SORT_CAP events (non-uniform hashgraphs: a round of two cliques or of a hashgraph with
+// slow members orders 4-6 k events at 256 members; the host sorted those: 88-107 ms per 1 M events, profiles/r04_final3_*):
+// the same bitonic network over a scratch copy of the keys in global memory (20 B per event, L2-resident), one workgroup per
+// such round, thread p of a stage owns the pair (i, i | j).  big_ri[b] = round-list entry, big_off[b] .. big_off[b + 1] =
+// its slice of the scratch arrays (length = the next power of two).  Ties stay with the host (flag), as above.
+__global__ void __launch_bounds__(1024)
+k_order_sort_big(const int* __restrict__ big_ri, const long long* __restrict__ big_off,
+                 const int* __restrict__ acc_ev, const long long* __restrict__ acc_off,
+                 const double* __restrict__ ts, const unsigned char* __restrict__ sig,
+                 const unsigned char* __restrict__ white, double* k_ts, u64* k_k8, int* k_ev, int* out_ev, int* host_flag) {
+    const int ri = big_ri[blockIdx.x], tid = threadIdx.x;
+    const long long s0 = big_off[blockIdx.x];
+    const int m = (int)(big_off[blockIdx.x + 1] - s0);
+    const long long a0 = acc_off[ri];
+    const int cnt = (int)(acc_off[ri + 1] - a0);
+    double* T = k_ts + s0;
+    u64* K8 = k_k8 + s0;
+    int* E = k_ev + s0;
+    u64 wk = 0;
+    for (int b = 0; b < 8; ++b) wk = (wk << 8) | white[(size_t)ri * 64 + b];
+    for (int i = tid; i < m; i += 1024) {
+        if (i < cnt) {
+            const int e = acc_ev[a0 + i];
+            u64 k = 0;
+            for (int b = 0; b < 8; ++b) k = (k << 8) | sig[(size_t)e * 64 + b];
+            T[i] = ts[a0 + i];
+            K8[i] = k ^ wk;
+            E[i] = e;
+        } else {
+            T[i] = __longlong_as_double(0x7ff0000000000000ll);  // +inf padding sorts last
+            K8[i] = ~0ull;
+            E[i] = 0x7fffffff;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < (m >> 1); p += 1024) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const double ta = T[i], tb = T[l];
+                const u64 ka = K8[i], kb = K8[l];
+                const int ea = E[i], eb = E[l];
+                const bool gt = ta > tb || (ta == tb && (ka > kb || (ka == kb && ea > eb)));
+                if (gt == up) {
+                    T[i] = tb; T[l] = ta;
+                    K8[i] = kb; K8[l] = ka;
+                    E[i] = eb; E[l] = ea;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int tie = 0;
+    for (int i = tid; i < cnt; i += 1024) {
+        out_ev[a0 + i] = E[i];
+        if (i + 1 < cnt && T[i] == T[i + 1] && K8[i] == K8[i + 1]) tie = 1;
+    }
+    const int any = __syncthreads_or(tie);
+    if (tid == 0) host_flag[ri] = any;   // (k_order_sort, launched before, flagged the round as oversize)
+}
+
 // ---------------------------------------------------------------------------------
 // Gossip side: what a peer needs from this node, from the device-resident state.
 // k_known_heights: {member -> height of the newest event of that member my head can see}

@@ -237,6 +237,10 @@ struct sw_ctx {
     std::vector<unsigned char> sig_h;        // host copy of the signatures (whitening, sort key)
     std::vector<int32_t> chain_start_h, chain_ev_h;
     DBuf<int32_t> d_fw_ev, d_fw_off, d_q, d_acc_ev, d_acc_ri, d_sorted, d_hostflag;
+    DBuf<int32_t> d_big_ri, d_sk_ev;     // find_order: rounds too large for the LDS sort and their scratch keys (k_order_sort_big)
+    DBuf<long long> d_big_off;
+    DBuf<double> d_sk_ts;
+    DBuf<u64> d_sk_k8;
     DBuf<int32_t> d_seg;   // find_order: [start | offset] of the newly ordered chain segments per (round entry, member)
     DBuf<int32_t> d_fw_cr, d_fd, d_ordhi;   // bulk find_order: creators of the famous witnesses, first-descendant table, end of the ordered chain segments
     DBuf<long long> d_acc_off;
@@ -1788,6 +1792,34 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
                            (const long long*)c->d_acc_off.p, (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p,
                            (const unsigned char*)c->d_white.p, c->d_sorted.p, c->d_hostflag.p);
         c->ctr.kernel_launches += 2;
+        {   // rounds too large for the LDS sort: the same network over global scratch, one workgroup per such round
+            std::vector<int32_t> big_ri;
+            std::vector<long long> big_off{0};
+            for (int i = 0; i < nr; ++i) {
+                const int64_t len = acc_off[i + 1] - acc_off[i];
+                if (len <= SORT_CAP || getenv("SW_ORDER_BIG_HOST")) continue;   // (test hook: oversize rounds to the host, as before round 4)
+                int64_t m = 1;
+                while (m < len) m <<= 1;
+                big_ri.push_back(i);
+                big_off.push_back(big_off.back() + m);
+            }
+            if (!big_ri.empty()) {
+                CHK(dgrow(c, c->d_big_ri, big_ri.size(), 0));
+                CHK(dgrow(c, c->d_big_off, big_off.size(), 0));
+                CHK(dgrow(c, c->d_sk_ts, (size_t)big_off.back(), 0));
+                CHK(dgrow(c, c->d_sk_k8, (size_t)big_off.back(), 0));
+                CHK(dgrow(c, c->d_sk_ev, (size_t)big_off.back(), 0));
+                // (pageable sources: the copies are staged before the call returns)
+                HIPCHK(c, hipMemcpyAsync(c->d_big_ri.p, big_ri.data(), big_ri.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->d_big_off.p, big_off.data(), big_off.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(k_order_sort_big, dim3((unsigned)big_ri.size()), dim3(1024), 0, c->stream, (const int*)c->d_big_ri.p,
+                                   (const long long*)c->d_big_off.p, (const int*)c->d_acc_ev.p, (const long long*)c->d_acc_off.p,
+                                   (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p, (const unsigned char*)c->d_white.p,
+                                   c->d_sk_ts.p, c->d_sk_k8.p, c->d_sk_ev.p, c->d_sorted.p, c->d_hostflag.p);
+                c->ctr.kernel_launches++;
+                HIPCHK(c, hipStreamSynchronize(c->stream));   // (big_ri / big_off are locals)
+            }
+        }
         lap("sort kernels");
         int err = 0;
         HIPCHK(c, hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
@@ -1801,7 +1833,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         }
         bool any_flag = false;
         if (getenv("SW_ORDER_HOST")) std::fill(hostflag.begin(), hostflag.end(), 1);  // test hook: host sort
-        for (int i = 0; i < nr; ++i) any_flag = any_flag || hostflag[i];
+        for (int i = 0; i < nr; ++i) { any_flag = any_flag || hostflag[i]; c->ctr.order_rounds_host_sorted += hostflag[i] ? 1 : 0; }
         if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts and the signatures
             acc_ev.resize((size_t)n_acc);
             ts.resize((size_t)n_acc);
@@ -2121,6 +2153,7 @@ int sw_destroy(sw_ctx* c) {
     if (c->d_err) (void)hipFree(c->d_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
     dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_acc_off); dfree(c->d_white);
+    dfree(c->d_big_ri); dfree(c->d_sk_ev); dfree(c->d_big_off); dfree(c->d_sk_ts); dfree(c->d_sk_k8);
     dfree(c->d_fw_cr); dfree(c->d_fd); dfree(c->d_ordhi); dfree(c->d_seg);
     dfree(c->d_rbnd); dfree(c->d_rcuts);
     if (c->d_rprov) (void)hipFree(c->d_rprov);

@@ -75,3 +75,29 @@ def test_host_sort_fallback_matches(pkg, monkeypatch):
     h2.append_events(cr, sp, op, t, sig)
     h2.divide_rounds(0, N)
     assert list(h2.find_order(h2.decide_fame())) == list(o.transactions)
+
+
+@pytest.mark.parametrize("big_host", [False, True])
+def test_rounds_larger_than_the_lds_sort(pkg, monkeypatch, big_host):
+    """A hashgraph with slow members orders more than 4096 events per round at 256 members: those rounds are sorted by
+    k_order_sort_big on the device (global scratch keys), not by the host — and give the oracle's order either way
+    (SW_ORDER_BIG_HOST=1: the host path such rounds took before)."""
+    from oracle.oracle import Oracle
+    if big_host:
+        monkeypatch.setenv("SW_ORDER_BIG_HOST", "1")
+    n, N = 256, 70000
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, 87, 2, 0.35, 0.02)
+    t = t + (np.arange(N) % 5) * 0.5
+    o, h = Oracle(n), pkg.Hashgraph(n)
+    for d in (o, h):
+        d.append_events(cr, sp, op, t, sig)
+        d.divide_rounds(0, N)
+    nco, nch = o.decide_fame(), h.decide_fame()
+    assert list(nco) == list(nch) and len(nch) >= 4
+    tx_o = o.find_order(nco)
+    tx_h = h.find_order(nch)
+    assert len(tx_o) > 4096 * 3 and len(tx_o) / len(nch) > 4096   # (the rounds really are that large)
+    assert list(tx_h) == list(tx_o)
+    hs = h.counters()["order_rounds_host_sorted"]
+    assert (hs > 0) if big_host else (hs == 0)
+    h.close()
