@@ -430,6 +430,10 @@ class Node:
         # below its earliest fork point, which every branch contains — instead of at the reported height.
         # Without it two honest nodes holding different siblings can never exchange them, and each
         # refuses everything the other builds afterwards (unknown parent).
+        # COST: from the first fork of member c on, every answer re-sends c's events above the fork point to every
+        # asker, for good (a second root: c's whole chain) — the asker drops what it already has, but pickling, signing and
+        # transfer grow with c's history.  One equivocator therefore makes sync payloads O(history of that member); bounding
+        # it needs the asker to report its branch tips for forked members (a protocol change the reference does not have).
         trunk = self._trunk_height
 
         def missing_parents(u):
