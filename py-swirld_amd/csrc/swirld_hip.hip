@@ -1199,6 +1199,8 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     // `halo` events before its start (k_cansee_chunks); their chain positions come from one more search kernel
     c->chunk_plan.assign(S, sw_ctx::ChunkPlan{});
     bool may_chunk = flow && !preswept && np <= 256 && c->chunks > 1 && !c->chunks_off && S <= SW_PROV_ROWS;
+    if (c->debug_timing && S > SW_PROV_ROWS)   // (only the SW_CUTS tuning hook can ask for that many sub-batches)
+        fprintf(stderr, "[sw] %d sub-batches: more than %d, swept unchunked\n", S, SW_PROV_ROWS);
     if (may_chunk && c->vm.active && !c->vm_scratch_ok) {   // windowed table: the scratch rows are mapped by the first call that can use them
         bool any = false;
         for (int i = 0; i < S; ++i) any = any || (cut[i + 1] - cut[i]) / c->chunk_min >= 2;
@@ -1335,7 +1337,8 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         clk.mark(&c->stage_us[2]);
         if (c->chunk_plan[i].G >= 2) {
             // the sweep of this sub-batch is complete (the loop waited for it) and its counters came back with the
-            // loop state: provisional entries per chunk, entries the repair changed
+            // loop state: provisional entries per chunk, entries the repair changed.  (run_round_loop never returns SW_OK
+            // without at least one read-back behind a shot that waited for cs_events[i]: h_rb is this sub-batch's.)
             const unsigned* pv = reinterpret_cast<const unsigned*>(c->h_rb + ((unsigned char*)c->d_prov - c->d_rb));
             const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
             for (int k = 1; k < pl.G; ++k) {
@@ -1977,7 +1980,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     knob("SW_MID_PCT", 0, 99, &c->mid_pct);
     knob("SW_FIN_BAND", 0, 1, &c->fin_band);
     knob("SW_FIN_BLOCKS", 64, 8192, &c->fin_blocks);
-    knob("SW_PIPE", 1, 64, &c->pipe);
+    knob("SW_PIPE", 1, SW_PROV_ROWS - 1, &c->pipe);   // (head + pipe sub-batches: every one of them has a row of chunk counters)
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
     knob("SW_CANSEE_IMPL", 2, 6, &c->cansee_impl);
     if (c->cansee_impl == 4 || c->cansee_impl == 5) knob_err = "SW_CANSEE_IMPL: 6 (dataflow sweep), 2 or 3 (level-bucketed sweep)";
