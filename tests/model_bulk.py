@@ -198,7 +198,10 @@ def bulk_rounds_v2(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None):
         is resolved for this round, and definitely false when q lies before that creator's
         cursor; otherwise the member waits for the next iteration;
       * a far candidate whose parents both have round <= r needs a real tally: the band is
-        doubled (up to CAPMAX) so that it becomes near."""
+        doubled (up to CAPMAX) so that it becomes near.
+    `band_out` (a dict): FINALIZE FROM THE BAND (k_resolve_band since round 4): every band pass leaves round_band[k] = r and
+    S_band[k] = its mask for the band events at or after their creator's round-r witness; the pass of an event's own round is
+    the last to write it.  Filled with {"round": int array (-1: never written), "S": bool (N, n)}."""
     N = len(cr)
     stake = np.asarray(stake, np.int64)
     T = int(stake.sum())
@@ -232,6 +235,9 @@ def bulk_rounds_v2(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None):
             for k in range(mhi_done, mhi):            # band (extension)
                 if k >= lo_r[cr[k]]:
                     masks[k] = L[k] >= lo_r
+                    if band_out is not None:
+                        band_out["round"][k] = len(lo) - 1
+                        band_out["S"][k] = masks[k]
             mhi_done = max(mhi_done, mhi)
             found = {c: None for c in unres}
             farslot = {c: None for c in unres}
@@ -302,7 +308,7 @@ def bulk_rounds_v2(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None):
     return L, np.array(lo, np.int64).astype(np.int32), stats
 
 
-def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_after=2, skip=0):
+def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_after=2, skip=0, band_out=None):
     """bulk_rounds_v2 plus GALLOPING for long runs of false candidates (a few members creating
     most of the events: thousands of chain positions per round, K per iteration).  After
     `gallop_after` consecutive windows without a passing candidate a member's window becomes
@@ -324,7 +330,10 @@ def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_
         is resolved for this round, and definitely false when q lies before that creator's
         cursor; otherwise the member waits for the next iteration;
       * a far candidate whose parents both have round <= r needs a real tally: the band is
-        doubled (up to CAPMAX) so that it becomes near."""
+        doubled (up to CAPMAX) so that it becomes near.
+    `band_out` (a dict): FINALIZE FROM THE BAND (k_resolve_band since round 4): every band pass leaves round_band[k] = r and
+    S_band[k] = its mask for the band events at or after their creator's round-r witness; the pass of an event's own round is
+    the last to write it.  Filled with {"round": int array (-1: never written), "S": bool (N, n)}."""
     N = len(cr)
     stake = np.asarray(stake, np.int64)
     T = int(stake.sum())
@@ -335,6 +344,9 @@ def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_
     lo = [np.array([ch[0] if len(ch) else INF for ch in chains], np.int64)]
     pos = np.zeros(n, np.int64)
     stats = dict(iters=0, evals=0, waits=0, grows=0, strided=0, refines=0)
+    if band_out is not None:
+        band_out["round"] = np.full(N, -1, np.int32)
+        band_out["S"] = np.zeros((N, n), bool)
     while True:
         lo_r = lo[-1]
         active = lo_r < INF
@@ -368,6 +380,9 @@ def bulk_rounds_v3(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None, gallop_
             for k in range(mhi_done, mhi):            # band (extension)
                 if k >= lo_r[cr[k]]:
                     masks[k] = L[k] >= lo_r
+                    if band_out is not None:
+                        band_out["round"][k] = len(lo) - 1
+                        band_out["S"][k] = masks[k]
             mhi_done = max(mhi_done, mhi)
             found = {c: None for c in unres}
             farslot = {c: None for c in unres}

@@ -121,3 +121,27 @@ def test_window_offset_model(pkg, n, N, seed, mode, p0, p1, K, cap, skip):
     rnd, S, wit = mb.finalize(n, cr, L3, lo3)
     assert np.array_equal(rnd, o.round)
     assert np.array_equal(wit, o.witnesses())
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,K,cap", [
+    (12, 4000, 33, 0, 0, 0, 6, None), (24, 5000, 40, 0, 0, 0, 10, None), (20, 5000, 41, 3, 0.6, 0, 8, None),
+    (24, 4000, 7, 2, 0.2, 0.002, 8, None), (16, 6000, 31, 2, 0.2, 50.0, 4, None), (9, 3000, 5, 1, 0.05, 0, 5, None),
+    (12, 4000, 33, 0, 0, 0, 6, 48), (24, 4000, 7, 2, 0.2, 0.002, 8, 64), (20, 5000, 41, 3, 0.6, 0, 8, 100),
+])
+def test_round_numbers_and_sees_masks_from_the_band_pass_model(pkg, n, N, seed, mode, p0, p1, K, cap):
+    """The rule k_resolve_band applies since round 4: every band pass writes round = r and the pass's mask for
+    the band events at or after their creator's round-r witness; rounds only go up, so what is left behind is the event's own
+    round and sees-mask wherever a band of that round covered the event.  (1) Where the band's round equals the searched round
+    — what k_finalize_check tests — the band's mask IS the sees-mask computed from the row; (2) with an unbounded band every
+    event is covered; with a capped band the uncovered ones are exactly those the check sends back to their rows."""
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    band = {}
+    L3, lo3, st3 = mb.bulk_rounds_v3(n, cr, sp, op, np.ones(n, np.int64), K=K, NEARCAP=cap or N, skip=1, band_out=band)
+    rnd, S, wit = mb.finalize(n, cr, L3, lo3)
+    covered = band["round"] == rnd
+    assert np.array_equal(band["S"][covered], S[covered])
+    assert (band["round"] <= rnd).all()          # a pass of a later round never writes an event of an earlier one
+    if cap is None:
+        assert covered.all()
+    else:
+        assert covered.mean() > 0.5              # (the capped band still covers most events; the rest go back to their rows)
