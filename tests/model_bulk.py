@@ -235,9 +235,6 @@ def bulk_rounds_v2(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None):
             for k in range(mhi_done, mhi):            # band (extension)
                 if k >= lo_r[cr[k]]:
                     masks[k] = L[k] >= lo_r
-                    if band_out is not None:
-                        band_out["round"][k] = len(lo) - 1
-                        band_out["S"][k] = masks[k]
             mhi_done = max(mhi_done, mhi)
             found = {c: None for c in unres}
             farslot = {c: None for c in unres}
