@@ -109,3 +109,27 @@ def load():
             f.argtypes = args
         _lib = L
     return _lib
+
+
+def hip_runtime_paths():
+    """The HIP runtime libraries mapped into this process (paths of libamdhip64*).  PyTorch wheels carry their own copy with
+    the SONAME of the system one: loaded FIRST, it also serves this library (one runtime, stream handles and events can be
+    shared); loaded AFTER this library it becomes a SECOND runtime — its streams mean nothing to the C-ABI, and it may not even
+    find the GPU once a windowed table has reserved its address range.  Import torch before this package when both are used."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def require_single_hip_runtime(what):
+    p = hip_runtime_paths()
+    if len(p) > 1:
+        raise RuntimeError("%s: two HIP runtimes are loaded in this process (%s) — torch was imported after py-swirld_amd; "
+                           "import torch first, so that both use one runtime and stream handles can cross the C-ABI" % (what, ", ".join(p)))
+

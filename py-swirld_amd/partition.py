@@ -139,6 +139,8 @@ class HipRangeBackend:
 
     def __init__(self, hashgraph, device):
         import torch
+        from . import _lib
+        _lib.require_single_hip_runtime("HipRangeBackend")   # (a torch stream handle is passed through the C-ABI)
         self.h, self.device, self.torch = hashgraph, device, torch
 
     def _stream(self):

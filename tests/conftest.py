@@ -38,9 +38,10 @@ def pytest_collection_finish(session):
     if names and _POOL is None and not session.config.option.collectonly:
         from oracle_pool import OraclePool
         _POOL = OraclePool(names)
-    # torch ships its own copy of the HIP runtime: it is initialised before the first windowed context reserves its address
-    # range (tests/test_gpu_window.py), whatever the order of the files — afterwards torch.cuda reports "No HIP GPUs are
-    # available" (profiles/r04r_pytest.log).  Only when tests that use torch on the GPU were selected.
+    # torch ships its own copy of the HIP runtime under the system library's SONAME: imported BEFORE py-swirld_amd's library it
+    # serves both (one runtime: torch streams can cross the C-ABI); imported after, it is a second runtime — and reports "No HIP
+    # GPUs are available" once a windowed context has reserved its address range (profiles/r04r_pytest.log).  So: torch first,
+    # whatever the order of the files.  Only when tests that use torch on the GPU were selected.
     uses_torch = any(it.get_closest_marker("gpu") is not None and
                      os.path.basename(str(it.fspath)) in ("test_gpu_strong_split.py", "test_gpu_partition.py") for it in session.items)
     if uses_torch and not session.config.option.collectonly:

@@ -126,3 +126,19 @@ def test_ctypes_structs_mirror_the_header_structs(pkg):
         fields = [(m.group(2), ctype[m.group(1)]) for m in re.finditer(r"\b(int64_t|int32_t|float)\s+([a-z_0-9]+)\s*;", body)]
         assert fields == list(mirror._fields_), name
         assert C.sizeof(mirror) == sum(C.sizeof(t) for _, t in fields), name
+
+
+def test_hip_runtime_listing(pkg):
+    """_lib.hip_runtime_paths(): at least the runtime the library itself is linked against; the guard used where torch
+    streams cross the C-ABI names both copies when there are two."""
+    import importlib
+    L = importlib.import_module("py-swirld_amd._lib")
+    L.load()
+    paths = L.hip_runtime_paths()
+    assert len(paths) >= 1 and all("libamdhip64" in p for p in paths)
+    if len(paths) > 1:
+        with pytest.raises(RuntimeError) as ei:
+            L.require_single_hip_runtime("test")
+        assert all(p in str(ei.value) for p in paths)
+    else:
+        L.require_single_hip_runtime("test")
