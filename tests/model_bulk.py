@@ -188,6 +188,60 @@ def elections(n, wit, Sw, stake, coin, famous, consensus, coin_period=6):
     return new_c, p2
 
 
+def elections_closed(n, wit, Sw, stake, coin, famous, consensus, r_closed, coin_period=6):
+    """PROTOTYPE (profiles/NOTES_next_round.md, experiment 2): elections that may run BEFORE every event of the call has been
+    divided — beside the last round loop — without changing anything decide_fame reports.  Only voters of CLOSED rounds take
+    part (rv <= r_closed: every member already has an event of round >= rv, so no witness of a round <= rv can appear later
+    and the voters' masks are final), and a round is committed ALL OR NOTHING: decisions, consensus flag and the P2 count of
+    a round are kept only if every witness of the round got decided; otherwise the round is left exactly as it was, for the
+    real decide_fame.  Returns (rounds committed, P2 of those rounds)."""
+    R = wit.shape[0]
+    stake = np.asarray(stake, np.int64)
+    T = int(stake.sum())
+    committed, p2_total = [], 0
+    for r in range(0, min(R, r_closed)):
+        if consensus[r]:
+            continue
+        row = famous[r].copy()
+        p2 = 0
+        any_dec = False
+        for cx in range(n):
+            x = wit[r, cx]
+            if x < 0 or row[cx] >= 0:
+                continue
+            V = None
+            for d in range(1, r_closed - r + 1):
+                rv = r + d
+                voters = wit[rv] >= 0
+                if d == 1:
+                    V = Sw[rv][:, cx] & voters
+                    continue
+                yes = (Sw[rv] & V[None, :]) @ stake
+                tot = Sw[rv] @ stake
+                no = tot - yes
+                v = ~(no > yes)
+                t = np.where(v, yes, no)
+                sm = (3 * t > 2 * T) & voters
+                if d % coin_period != 0:
+                    if sm.any():
+                        idx = np.where(sm, wit[rv], INF)
+                        first = int(np.argmin(idx))
+                        row[cx] = 1 if v[first] else 0
+                        p2 += int((voters & (wit[rv] <= wit[rv][first])).sum())
+                        any_dec = True
+                        break
+                    V = v & voters
+                else:
+                    V = np.where(sm, v, coin[np.maximum(wit[rv], 0)].astype(bool)) & voters
+                p2 += int(voters.sum())
+        if any_dec and all(row[c] >= 0 for c in range(n) if wit[r, c] >= 0):
+            famous[r] = row
+            consensus[r] = 1
+            committed.append(r)
+            p2_total += p2
+    return committed, p2_total
+
+
 def bulk_rounds_v2(n, cr, sp, op, stake, K=4, NEARCAP=None, CAPMAX=None):
     """Round loop with the inheritance shortcut for FAR candidates (kernel structure of
     k_resolve_band / k_tally_* since the slow-member fix):

@@ -145,3 +145,56 @@ def test_round_numbers_and_sees_masks_from_the_band_pass_model(pkg, n, N, seed, 
         assert covered.all()
     else:
         assert covered.mean() > 0.5              # (the capped band still covers most events; the rest go back to their rows)
+
+
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1,parts", [
+    (9, 2400, 61, 0, 0, 0, 4), (12, 3000, 62, 2, 0.3, 0.02, 5), (16, 3200, 63, 1, 0.03, 0, 4), (20, 3000, 64, 3, 0.6, 0, 3),
+    (10, 3000, 65, 2, 0.5, 0.01, 6),
+])
+def test_elections_of_closed_rounds_before_the_last_events_model(pkg, n, N, seed, mode, p0, p1, parts):
+    """Prototype of an overlap the device does not have yet (mb.elections_closed): after every prefix of the call's events the
+    rounds every member has left are CLOSED — their witness rows and voter masks equal the final ones — and their elections,
+    committed all or nothing per round, leave the real decide_fame nothing to redo: decisions, consensus rounds and the P2
+    counter of the ONE decide_fame call the reference makes come out identical."""
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    stake = np.ones(n, np.int64)
+    coin = sig[:, 0] >= 128
+    o = Oracle(n)
+    o.append_events(cr, sp, op, t, sig)
+    o.divide_rounds(0, N)
+    nc = o.decide_fame()
+    L, lo, _ = mb.bulk_rounds_v3(n, cr, sp, op, stake, K=4, skip=1)
+    rnd_f, S_f, wit_f = mb.finalize(n, cr, L, lo)
+    Sw_f = mb.voter_masks(n, L, rnd_f, S_f, wit_f, stake)
+    R = wit_f.shape[0]
+    fam = np.full((R, n), -1, np.int8)
+    cons = np.zeros(R, np.uint8)
+    pre_rounds, p2_total, closed_seen = [], 0, 0
+    for k in range(1, parts):
+        cut = N * k // parts
+        Lp, lop, _ = mb.bulk_rounds_v3(n, cr[:cut], sp[:cut], op[:cut], stake, K=4, skip=1)
+        rnd, S, wit = mb.finalize(n, cr[:cut], Lp, lop)
+        front = np.full(n, -1, np.int64)
+        np.maximum.at(front, cr[:cut], rnd)
+        r_closed = int(front.min())
+        if r_closed < 1:
+            continue
+        Sw = mb.voter_masks(n, Lp, rnd, S, wit, stake)
+        # closure: what the prefix knows of the rounds <= r_closed is what the whole call knows
+        assert np.array_equal(wit[:r_closed + 1], wit_f[:r_closed + 1])
+        assert np.array_equal(Sw[1:r_closed + 1], Sw_f[1:r_closed + 1])
+        closed_seen = max(closed_seen, r_closed)
+        Rp = wit.shape[0]
+        done, p2 = mb.elections_closed(n, wit, Sw, stake, coin, fam[:Rp], cons[:Rp], r_closed)
+        pre_rounds += done
+        p2_total += p2
+    # (the prototype did decide rounds early — except where half of the members are 100 x slower: the rounds they have all left
+    # are few, and deciding them takes more levels than are closed)
+    assert closed_seen >= 2 and (len(pre_rounds) >= 1 or p0 >= 0.5)
+    new_c, p2 = mb.elections(n, wit_f, Sw_f, stake, coin, fam, cons)
+    p2_total += p2
+    m = wit_f >= 0
+    assert np.array_equal(fam[m], o.famous_by_event[wit_f[m]])
+    assert np.array_equal(cons, o.consensus())
+    assert sorted(pre_rounds + list(new_c)) == list(nc)
+    assert p2_total == o.counters()["majority_evals"]
