@@ -198,3 +198,32 @@ def test_elections_of_closed_rounds_before_the_last_events_model(pkg, n, N, seed
     assert np.array_equal(cons, o.consensus())
     assert sorted(pre_rounds + list(new_c)) == list(nc)
     assert p2_total == o.counters()["majority_evals"]
+
+
+def test_sixteen_bit_band_rows_model():
+    """Prototype for 1024 members (profiles/NOTES_next_round.md, experiment 3; at 256 members the band phase is bound by
+    requests and the table lost): band rows kept as 16-bit distances L16[k][c] = min(k - L[k][c], 65535).  The band's
+    compare L[k][c] >= lo[r][c] becomes L16 <= k - lo[r][c] — exact, saturated entries included, as long as the band is
+    shorter than 65535 events (thresholds are at or after its first event); longer bands take the 32-bit rows."""
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n = int(rng.integers(2, 40))
+        mlo = int(rng.integers(0, 3_000_000))
+        blen = int(rng.integers(1, 65535))
+        ks = mlo + rng.integers(0, blen, size=64)
+        # thresholds: inside the band, at its start, or INF (no round-r witness)
+        thr = mlo + rng.integers(0, blen, size=n).astype(np.int64)
+        thr[rng.random(n) < 0.2] = int(mb.INF)
+        thr[rng.random(n) < 0.1] = mlo
+        for k in ks:
+            k = int(k)
+            # entries: recent, far in the past (saturating), never seen (-1), the event itself
+            L = k - rng.integers(0, 200_000, size=n).astype(np.int64)
+            L[rng.random(n) < 0.1] = -1
+            L[rng.random(n) < 0.05] = k
+            L = np.clip(L, -1, k)
+            L16 = np.minimum(k - L, 65535).astype(np.uint16)
+            want = L >= thr
+            d = k - thr                                   # negative: the threshold lies after the event
+            got = (d >= 0) & (L16.astype(np.int64) <= d)
+            assert np.array_equal(got, want), (trial, k)
