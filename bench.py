@@ -409,7 +409,8 @@ def main():
                      "chains (DAG levels, rounds), not by bandwidth",
         "counters": {k: cd[k] for k in ("levels", "round_iterations", "tally_evals", "band_events", "voter_evals",
                                         "majority_evals", "coin_votes", "coin_flips", "far_hops",
-                                        "chunk_sweeps", "chunk_provisional", "chunk_repaired", "chunk_resweeps")},
+                                        "chunk_sweeps", "chunk_provisional", "chunk_repaired", "chunk_resweeps",
+                                        "finalize_from_rows") if k in cd},
         "phase_ms": {k: round(v, 3) for k, v in (("can_see_stream_span", tm["can_see_ms"]), ("round_loop_span", tm["rounds_ms"]),
                                                  ("aux_finalize_voter_span", tm["finalize_ms"]), ("fame", tm["fame_ms"]))},
         "phase_note": "profiled pass = plain launches with event pairs (slower than the graph-replayed timed steps); "
