@@ -41,6 +41,7 @@ import importlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -198,6 +199,7 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=3, help="end-to-end passes (host arrays in, results on host); 0 = skip")
     ap.add_argument("--split", choices=["replicas", "strong"], default="replicas",
                     help="which multi-GPU number is `value`: independent replicas (default) or ONE hashgraph over the GPUs")
+    ap.add_argument("--strong-timeout", type=int, default=150, help="seconds the one-hashgraph split (world > 1) may take before the line is printed without it (0 = no watchdog)")
     ap.add_argument("--emulate-parts", type=int, default=0,
                     help="1 GPU only: also run the one-hashgraph split with this many contexts on the one device (no parallelism: "
                          "a functional run that reports the per-range sweep time and the rows moved)")
@@ -265,7 +267,6 @@ def main():
     # idle.  Reported next to `value`, never as `value`: a node divides ONE hashgraph, and ms_per_step is that pass's latency.
     conc = None
     if args.concurrent > 1 and n_ctx >= args.concurrent and world == 1:
-        import threading
         per = max(2, args.steps // args.concurrent)
 
         def worker(j):
@@ -312,14 +313,6 @@ def main():
                "includes": "sw_reset + sw_append_events (93 B/event over PCIe: parents, t, 64-byte signature) + "
                            "sw_divide_rounds + sw_decide_fame + round[N] / witness table / famous read-back"}
         assert len(r_e2e[0]) == N and list(r_e2e[3]) == list(new_c)
-
-    # ---- ONE hashgraph over the GPUs (north_star's split): the same stream on every rank ----
-    strong = None
-    part_mod = importlib.import_module("py-swirld_amd.partition")
-    try:
-        strong = strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, N, stream, new_c, barrier)
-    except Exception as exc:  # noqa: BLE001 — the replicas line is still printed; the failure is part of it
-        strong = {"error": repr(exc)}
 
     # ---- per-kernel roofline table: one extra profiled pass (plain launches, hipEvent pairs) ----
     h = ctxs[0]
@@ -453,11 +446,18 @@ def main():
             except (OSError, ValueError):
                 pass
 
-    use_strong = args.split == "strong" and strong is not None and "events_per_s" in strong
     value_replicas, ms_replicas = value, ms_per_step
-    if use_strong:
-        value, ms_per_step = strong["events_per_s"], strong["ms_per_step"]
-    if rank == 0:
+    line_lock, line_done = threading.Lock(), [False]
+
+    def emit(strong):
+        """rank 0 prints THE JSON line, once (the watchdog of the split below may be the one that calls this)."""
+        with line_lock:
+            if line_done[0] or rank != 0:
+                line_done[0] = True
+                return
+            line_done[0] = True
+        use_strong = args.split == "strong" and strong is not None and "events_per_s" in strong
+        value, ms_per_step = (strong["events_per_s"], strong["ms_per_step"]) if use_strong else (value_replicas, ms_replicas)
         out = {
             "metric": "events/sec through divide_rounds+decide_fame", "value": round(value, 1),
             "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -488,7 +488,30 @@ def main():
                        "find_order_ms_untimed": round(find_order_ms, 2), "events_ordered": int(len(ordered))},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+    # ---- ONE hashgraph over the GPUs (north_star's split): the same stream on every rank.  LAST, and under a
+    # watchdog: everything the line needs besides `strong` exists by now, so a collective of the split that never completes
+    # (a rank that failed alone, a fabric problem) costs the run `value_strong`, not the line.
+    strong = None
+    part_mod = importlib.import_module("py-swirld_amd.partition")
+    watchdog = None
+    if world > 1 and args.strong_timeout > 0:
+        def bail():
+            emit({"error": "the one-hashgraph split did not finish within %d s (a collective did not complete); "
+                           "the replicas figures above are unaffected" % args.strong_timeout})
+            time.sleep(1.0 if rank == 0 else 3.0)   # (rank 0's line is out before any process of the job goes away)
+            os._exit(0)
+        watchdog = threading.Timer(args.strong_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        strong = strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, N, stream, new_c, barrier)
+    except Exception as exc:  # noqa: BLE001 — the replicas line is still printed; the failure is part of it
+        strong = {"error": repr(exc)}
+    if watchdog is not None:
+        watchdog.cancel()
+    emit(strong)
     rep.close()
 
 
