@@ -108,6 +108,29 @@ def time_python_reference(ref_path, n, stream, events):
         return {"same_run": False, "error": repr(exc)}
 
 
+def guarded(fn, timeout_s, on_timeout, linger_s=1.0):
+    """fn() on the calling thread.  If it has not returned after timeout_s seconds (0 = no limit), on_timeout() runs on a timer
+    thread and the PROCESS ends with status 0 `linger_s` later — for work that may block for ever inside a collective (the
+    thread cannot be interrupted, the process can): what had to be printed is printed by on_timeout."""
+    if timeout_s <= 0:
+        return fn()
+
+    def bail():
+        try:
+            on_timeout()
+            sys.stdout.flush()
+        finally:
+            time.sleep(linger_s)   # (rank 0's line is out before any process of the job goes away)
+            os._exit(0)
+    timer = threading.Timer(timeout_s, bail)
+    timer.daemon = True
+    timer.start()
+    try:
+        return fn()
+    finally:
+        timer.cancel()
+
+
 def strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, N, stream, new_c, barrier):
     """The one-hashgraph split, timed (world > 1) or emulated with several contexts on one device (--emulate-parts)."""
     strong = None
@@ -495,22 +518,17 @@ def main():
     # (a rank that failed alone, a fabric problem) costs the run `value_strong`, not the line.
     strong = None
     part_mod = importlib.import_module("py-swirld_amd.partition")
-    watchdog = None
-    if world > 1 and args.strong_timeout > 0:
-        def bail():
-            emit({"error": "the one-hashgraph split did not finish within %d s (a collective did not complete); "
-                           "the replicas figures above are unaffected" % args.strong_timeout})
-            time.sleep(1.0 if rank == 0 else 3.0)   # (rank 0's line is out before any process of the job goes away)
-            os._exit(0)
-        watchdog = threading.Timer(args.strong_timeout, bail)
-        watchdog.daemon = True
-        watchdog.start()
-    try:
-        strong = strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, N, stream, new_c, barrier)
-    except Exception as exc:  # noqa: BLE001 — the replicas line is still printed; the failure is part of it
-        strong = {"error": repr(exc)}
-    if watchdog is not None:
-        watchdog.cancel()
+    def on_timeout():
+        emit({"error": "the one-hashgraph split did not finish within %d s (a collective did not complete); "
+                       "the replicas figures above are unaffected" % args.strong_timeout})
+
+    def run_split():
+        try:
+            return strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, N, stream, new_c, barrier)
+        except Exception as exc:  # noqa: BLE001 — the replicas line is still printed; the failure is part of it
+            return {"error": repr(exc)}
+
+    strong = guarded(run_split, args.strong_timeout if world > 1 else 0, on_timeout, linger_s=1.0 if rank == 0 else 3.0)
     emit(strong)
     rep.close()
 
