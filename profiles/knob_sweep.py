@@ -12,6 +12,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("py-swirld_amd")
+if os.environ.get("SWEEP_LIB"):   # A/B of two builds on one box: another libswirld_hip.so for this process (the loader reads the path at its first call)
+    importlib.import_module("py-swirld_amd._lib").LIB_PATH = os.path.abspath(os.environ["SWEEP_LIB"])
+    print("library:", os.environ["SWEEP_LIB"], flush=True)
 
 args = sys.argv[1:]
 split = args.index("--") if "--" in args else len(args)

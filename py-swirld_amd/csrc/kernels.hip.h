@@ -542,6 +542,8 @@ __device__ __forceinline__ void load_cols_sc1_and_wait(const int* ptr, int (&v)[
 
 template <int C>
 __device__ __forceinline__ void store_cols(int* ptr, const int (&v)[C]) {
+    // (round 5, measured and dropped — profiles/r05a_knobs_256x1M.log: streaming (`nt`) stores for the rows, to keep the sweep out of
+    // the L2 the round loop gathers from: 7.00 -> 7.78 ms per pass — the rows of one chain are assembled in L2 from 16-byte pieces)
     if constexpr (C == 4) *reinterpret_cast<int4*>(ptr) = make_int4(v[0], v[1], v[2], v[3]);
     else *reinterpret_cast<int2*>(ptr) = make_int2(v[0], v[1]);
 }
@@ -1019,7 +1021,7 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
 // has work, derive the band.  Step 2: threshold masks of the band events, Mb[k-mlo] bit c_ =
 // (L[k][c_] >= lo[r][c_]) = "the latest event of c_ that k sees has round >= r" (one wave per
 // band event, NW ballots).
-template <int NW>
+template <int NW, bool FAST>
 __global__ void __launch_bounds__(1024)
 k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
@@ -1047,29 +1049,40 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     const bool writer = blockIdx.x == 0;
     const int c = threadIdx.x;
     const size_t in = (size_t)par * npad, out = (size_t)(1 - par) * npad;
-    const bool member = c < npad;
+    const bool member = (NW >= 4) || c < npad;   // (workgroups of max(npad, 256) threads: every thread is a member from 256 members on)
     // First memory round trip: the loop state and every per-member value whose address does not
     // depend on it, issued together BEFORE the first branch (a load behind an early return cannot
-    // be hoisted by the compiler and would cost a dependent round trip of its own).
+    // be hoisted by the compiler and would cost a dependent round trip of its own).  The per-member loads are
+    // UNCONDITIONAL, from a clamped index: fourteen `member ? x[c] : d` are fourteen exec-masked blocks with a taken
+    // branch each (round 5, from the ISA), and the threads beyond npad take the defaults by a select afterwards.
     const int s_done = si->done;
     int r = si->r;
     const int iter = si->iter;
     const int N = si->N;
     const int s_mlo = si->mlo, s_mhi = si->mhi, s_ncap = si->ncap;
     const int fin_from = si->fin_from;
-    const int cs = member ? chain_start[c] : 0;
-    const int clen = member ? chain_len[c] : 0;  // events of member c visible to this run
-    int un = member ? B.unres[in + c] : 0;
-    int curc = member ? B.cur[in + c] : 0;
-    const u64 fev = member ? B.found64[in + c] : ~0ull;
+    const int cq = member ? c : 0;
+    const int cs = chain_start[cq];
+    const int clen_ld = chain_len[cq];  // events of member c visible to this run
+    const int un_ld = B.unres[in + cq];
+    int curc = B.cur[in + cq];
+    const u64 fev_ld = B.found64[in + cq];
+    const int jf_ld = B.farslot[in + cq];
+    const int frc_ld = B.force[in + cq];
+    const int gsv_ld = B.gallop[in + cq];
+    const int evr_ld = B.evalround[in + cq], evp_ld = B.evalpos[in + cq];
+    const int in_lo_next = B.lo_next[in + cq];
+    const int in_pos_next = B.pos_next[in + cq];
+    const int thr_ld = B.lo_r[in + cq];
+    const int clen = member ? clen_ld : 0;
+    int un = member ? un_ld : 0;
+    const u64 fev = member ? fev_ld : ~0ull;
     const int fnd = fev == ~0ull ? SW_INF : (int)((fev >> 26) & 63);   // smallest candidate slot whose tally passed
-    const int jf = member ? B.farslot[in + c] : SW_INF;
-    int frc = member ? B.force[in + c] : 0;
-    const int gsv = member ? B.gallop[in + c] : 1;
-    int evr_now = member ? B.evalround[in + c] : -1, evp_now = member ? B.evalpos[in + c] : 0;
-    const int in_lo_next = member ? B.lo_next[in + c] : SW_INF;
-    const int in_pos_next = member ? B.pos_next[in + c] : 0;
-    int thr = member ? B.lo_r[in + c] : SW_INF;
+    const int jf = member ? jf_ld : SW_INF;
+    int frc = member ? frc_ld : 0;
+    const int gsv = member ? gsv_ld : 1;
+    int evr_now = member ? evr_ld : -1, evp_now = member ? evp_ld : 0;
+    int thr = member ? thr_ld : SW_INF;
     const bool stamp = c == 0 && blockIdx.x == 1;  // a block that does not publish the state
     const int sb = 0;
     if (B.dbg && stamp && !s_done && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb] = wall_clock64();
@@ -1081,11 +1094,16 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // (handing these three over with the loop state — stored by the writer block, read with the first round
     // trip — was measured: the writer's extra dependent loads lengthen the kernel by more than the round trip
     // saved here, 128.1 -> 126.3 M events/s)
-    const int lo_r1 = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
-    const int lo_r2 = (member && r + 2 < Rcap) ? lo[(size_t)(r + 2) * npad + c] : SW_INF;
-    const int lopos_r1 = (member && r + 1 < Rcap) ? lopos[(size_t)(r + 1) * npad + c] : 0;
-    int my_lo_next = iter > 0 ? in_lo_next : SW_INF;
-    int my_pos_next = iter > 0 ? in_pos_next : 0;
+    // (clamped rows, unconditional loads, selects afterwards: see above)
+    const int rq1 = r + 1 < Rcap ? r + 1 : Rcap - 1, rq2 = r + 2 < Rcap ? r + 2 : Rcap - 1;
+    const int lo_r1_ld = lo[(size_t)rq1 * npad + cq];
+    const int lo_r2_ld = lo[(size_t)rq2 * npad + cq];
+    const int lopos_r1_ld = lopos[(size_t)rq1 * npad + cq];
+    const int lo_r1 = (member && r + 1 < Rcap) ? lo_r1_ld : SW_INF;
+    const int lo_r2 = (member && r + 2 < Rcap) ? lo_r2_ld : SW_INF;
+    const int lopos_r1 = (member && r + 1 < Rcap) ? lopos_r1_ld : 0;
+    int my_lo_next = (iter > 0 && member) ? in_lo_next : SW_INF;
+    int my_pos_next = (iter > 0 && member) ? in_pos_next : 0;
     int mlo = s_mlo, mhi = s_mhi;
     int ncap = s_ncap;
     // tallies evaluated by the previous launch for this member: the slots before its first far one
@@ -1413,9 +1431,50 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         // creator's round-r witness has round >= r, and its mask against lo[r] — the ballots below — is its sees-mask if its round
         // IS r.  The pass of the event's true round is the last one to write it (rounds only go up), so after the loop
         // round[e] / S[e] are final for every event a band of its own round covered; k_finalize_check finds the others.
-        const int fin_thr = mine ? s_thr[cr[kk]] : SW_INF;   // lo[r][creator]: INF when the creator has no round-r witness
-        const u64 fin_m = __ballot(mine && kk >= fin_thr && kk >= fin_from);
+        // (the creator is fetched with a CLAMPED index, unconditionally: a load inside an exec-masked block is waited for at the
+        // block's end — one dependent round trip in front of the rows of every group)
+        // The `asm` after the row loads pins the first USE of the creator there: the compiler would otherwise wait for it (and
+        // for the LDS look-up behind it) before it issues the rows — two dependent round trips per group instead of one.
+        const int kc = kk < mask_from ? mask_from : (kk < mhi ? kk : mhi - 1);
+        int crk = cr[kc];
+        auto fin_mask = [&]() -> u64 {
+            asm volatile("" : "+v"(crk));
+            const int fin_thr = s_thr[crk];   // lo[r][creator]: INF when the creator has no round-r witness
+            return __ballot(mine && kk >= fin_thr && kk >= fin_from);
+        };
         constexpr int RIF = NW <= 4 ? 8 : 4;  // rows in flight per wave (one memory round trip per pass)
+        if constexpr (FAST && RIF == 8) {
+            // a FULL group — eight consecutive events, all of them band events (the common case): fixed indices, ONE 64-bit
+            // row base per group and compile-time offsets (npad = 64 NW) instead of the ffs / mask bookkeeping and a
+            // multiply-add per load (ISA: ~400 instead of ~1 260 instructions per group at NW = 4)
+            if (vm == 0xffull) {
+                constexpr int NP = 64 * NW;
+                const int* row0 = L + (size_t)base * NP + lane;
+                int v[8][NW];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) v[u][j] = row0[u * NP + j * 64];
+                const u64 fin_m = fin_mask();
+                u64* mb0 = Mb + (size_t)(base - mlo) * NW + lane;
+                u64* s0 = S_out + (size_t)base * NW + lane;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    u64 word = 0;
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const u64 bm = __ballot(v[u][j] >= t_[j]);
+                        word = lane == j ? bm : word;
+                    }
+                    if (lane < NW) mb0[u * NW] = word;
+                    if ((fin_m >> u) & 1ull) {
+                        if (lane < NW) s0[u * NW] = word;
+                        if (lane == NW) round_out[base + u] = r;
+                    }
+                }
+                continue;
+            }
+        }
         while (vm) {
             int ks[RIF];
 #pragma unroll
@@ -1429,6 +1488,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
                     v[u][j] = ks[u] >= 0 ? L[(size_t)ks[u] * npad + j * 64 + lane] : -1;
+                const u64 fin_m = fin_mask();   // (RIF covers a whole group: this loop makes one pass)
 #pragma unroll
             for (int u = 0; u < RIF; ++u)
                 if (ks[u] >= 0) {
@@ -1777,6 +1837,8 @@ __device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) +
     return gt;
 }
 
+// (round 5, measured and dropped — profiles/r05a_knobs_1024x2M.log: at 1024 members the kernel takes 99 VGPRs = 4 waves per SIMD; asking
+// the allocator for 5 waves (96 VGPRs, 8 B of scratch) changes nothing, for 6 (80 VGPRs, 18 spilled dwords) costs 6 %)
 template <int NW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 4 ? 8 : 2, 8)))
 k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
@@ -1817,6 +1879,20 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     // their gathers (2.9 us against 0.9 us for late waves, phase stamps).  The first 64 waves of each XCD touch
     // one 128-byte line per lane while they wait for their own first round trips (SW_TALLY_PF=0 switches it
     // off): 7.76 -> 7.69 ms per pass at 256 members / 1 M events.
+    // (the member's words are requested BEFORE the touch below: see k_tally_tree)
+    const int un = B.unres[pb + cm], frc = B.force[pb + cm];
+    const int* cand = B.cand + ((size_t)(1 - par) * npad + cm) * 64;
+    const int e = cand[cj + 1];  // published by k_resolve_band (-1: no such candidate)
+    // what the next resolve step will want if this slot is the member's first passing one: the last candidate of
+    // the window that would follow it (entry j + skip + K of a contiguous window's look-ahead; -1: not published)
+    const int la_i = cj + skip + K;
+    const bool use_la = NW <= 4 || K >= 32;   // (the table is published 63 positions far only then, see k_resolve_band)
+    const int la_ld = cand[(use_la && la_i < 64) ? la_i : 0];
+    const int la = (use_la && la_i < 64) ? la_ld : -1;
+    const int gsv = B.gallop[pb + cm];
+    int thr[NW], P[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
     int pf_dummy = 0;
     if (mb_prefetch) {
         const int wx = ((int)blockIdx.x >> 3) * 4 + wib;               // wave index within its XCD (block b runs on XCD b mod 8: locality only)
@@ -1827,18 +1903,6 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
             asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(q) : "memory");
         }
     }
-    const int un = B.unres[pb + cm], frc = B.force[pb + cm];
-    const int* cand = B.cand + ((size_t)(1 - par) * npad + cm) * 64;
-    const int e = cand[cj + 1];  // published by k_resolve_band (-1: no such candidate)
-    // what the next resolve step will want if this slot is the member's first passing one: the last candidate of
-    // the window that would follow it (entry j + skip + K of a contiguous window's look-ahead; -1: not published)
-    const int la_i = cj + skip + K;
-    const bool use_la = NW <= 4 || K >= 32;   // (the table is published 63 positions far only then, see k_resolve_band)
-    const int la = (use_la && la_i < 64) ? cand[(use_la && la_i < 64) ? la_i : 0] : -1;
-    const int gsv = B.gallop[pb + cm];
-    int thr[NW], P[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
     // stamped waves: candidate slot K/2 of the first and of the last member
     const bool stamp = B.dbg && lane == 0 && cj == (K >> 1) && (cm == 0 || cm == (int)(gridDim.x * 4 / K) - 1);
     const int sb = cm == 0 ? 16 : 24;
@@ -2025,6 +2089,13 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     const int wib = threadIdx.x >> 6;
     const int cm = blockIdx.x;
     const int s_done = st->done, mlo = st->mlo, mhi = st->mhi;
+    // (the member's words are requested BEFORE the touch below: the touch sits in an exec-masked block that needs the band range,
+    // i.e. a wait for the loop state — behind it these loads were a second dependent round trip at the head of the kernel)
+    const int un = B.unres[pb + cm], frc = B.force[pb + cm], gsv = B.gallop[pb + cm];
+    const int ce_lane = B.cand[((size_t)(1 - par) * npad + cm) * 64 + lane];   // entry 1 + j = the event of slot j
+    int thr[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
     int pf_dummy = 0;
     if (mb_prefetch) {   // the first 64 waves of every XCD touch the band-mask table (written by the other XCDs), see k_tally_bits
         const int wx = ((int)blockIdx.x >> 3) * 8 + wib;
@@ -2035,11 +2106,6 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
             asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(q) : "memory");
         }
     }
-    const int un = B.unres[pb + cm], frc = B.force[pb + cm], gsv = B.gallop[pb + cm];
-    const int ce_lane = B.cand[((size_t)(1 - par) * npad + cm) * 64 + lane];   // entry 1 + j = the event of slot j
-    int thr[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) thr[j] = B.lo_r[pb + j * 64 + lane];
     const bool stamp = B.dbg && lane == 0 && wib == 0 && (cm == 0 || cm == (int)gridDim.x - 1);
     const int sb = cm == 0 ? 16 : 24;
     const int it_ = stamp ? st->iter - 1 : 0;

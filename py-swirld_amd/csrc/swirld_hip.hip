@@ -213,10 +213,12 @@ struct sw_ctx {
     int mid_pct = 0;       // SW_MID_PCT: where the last sub-batch's round loop is interrupted once for an early finalize (0 = never: with
                            // SW_FIN_BAND=1 there is nothing left to hide; 88 was the default of the row-reading finalize)
     int fin_band = 1;      // SW_FIN_BAND: round[] and the sees-masks come from the round loop's band pass, the finalize launch only checks (1) / every event from its row (0)
+    int band_fast = 1;     // SW_BAND_FAST: k_resolve_band takes full groups of 8 band events through a path with fixed indices and compile-time offsets
+                           // (round 5, profiles/r05a_*: band phase 2.66 -> 1.90 us, 7.00 -> 6.72 ms per pass at 256 members / 1 M events; 0 = the generic path only)
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
     // round-loop graph
-    struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; void* S; void* round; int K, tally_impl, BATCH, MCAP; };
+    struct GraphKey { int Rcap; int64_t N; void* lo; void* L; void* chain; void* S; void* round; int K, tally_impl, BATCH, MCAP, variant; };
     bool use_graph = true;
     hipGraph_t loop_graph[4] = {nullptr, nullptr, nullptr, nullptr};
     hipGraphExec_t loop_exec[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -819,21 +821,31 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
     const LoopBufs B = loop_bufs(c);
     Span sr{};
     if (resolve_spans) sr = span_begin(c);
-    hipLaunchKernelGGL(k_resolve_band<NW>, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
-                       c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
-                       (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p);
+    auto resolve_band = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
+                           c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
+                           (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p);
+    };
+    if constexpr (NW <= 4) {
+        if (c->band_fast) resolve_band(k_resolve_band<NW, true>);
+        else resolve_band(k_resolve_band<NW, false>);
+    } else resolve_band(k_resolve_band<NW, false>);
     if (resolve_spans) { span_end(c, sr); resolve_spans->push_back(sr); }
     Span s{};
     if (tally_spans) s = span_begin(c);
     if (c->unit_stake && c->tally_impl == 2)
         hipLaunchKernelGGL(k_tally_tree<NW>, dim3(np), dim3(512), 0, c->stream, B, par, K, c->skip, c->tally_pf,
                            (const int*)c->d_L.p, (const int*)c->d_sp.p, (const int*)c->d_op.p, (const uint32_t*)c->d_Mb.p, tot2, np);
-    else if (c->unit_stake && c->tally_impl >= 1)
-        hipLaunchKernelGGL(k_tally_bits<NW>, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, c->tally_pf,
-                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                           (const uint32_t*)c->d_Mb.p, tot2, np);
+    else if (c->unit_stake && c->tally_impl >= 1) {
+        auto tally_bits = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, c->tally_pf,
+                               (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
+                               (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
+                               (const uint32_t*)c->d_Mb.p, tot2, np);
+        };
+        tally_bits(k_tally_bits<NW>);
+    }
     else if (c->unit_stake)
         hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
@@ -865,7 +877,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
     key.S = (void*)c->d_S.p; key.round = (void*)c->d_round.p;
-    key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP;
+    key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP; key.variant = c->band_fast;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
         for (int g = 0; g < 4; ++g) {
             if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
@@ -1988,6 +2000,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     knob("SW_FLOW_CFG", 0, 3, &c->flow_cfg);
     knob("SW_CHUNKS", 1, SW_MAX_CHUNKS, &c->chunks);
     knob("SW_CHUNK_CFG", 0, 2, &c->chunk_cfg);
+    knob("SW_BAND_FAST", 0, 1, &c->band_fast);
     knob("SW_CHUNK_MIN", 64, 1 << 30, &c->chunk_min);
     c->halo = 32 * (int64_t)c->npad;
     knob("SW_HALO", 0, 1 << 24, &c->halo);

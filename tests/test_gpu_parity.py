@@ -257,12 +257,13 @@ def test_tuning_knobs_do_not_change_results(pkg, monkeypatch):
     assert from_rows > 0
 
 
-@pytest.mark.parametrize("fin_band", ["0", "1"])
-def test_round_numbers_from_the_band_pass_or_from_the_rows(pkg, monkeypatch, fin_band):
+@pytest.mark.parametrize("fin_band,band_fast", [("0", "1"), ("1", "1"), ("1", "0"), ("0", "0")])
+def test_round_numbers_from_the_band_pass_or_from_the_rows(pkg, monkeypatch, fin_band, band_fast):
     """round[] and the sees-masks (swirld.py:217-219; the voters' hop masks of decide_fame) written by the round loop's band
     pass and checked afterwards (SW_FIN_BAND=1, the default) against every event finalized from its row (0): batch and
     incremental schedules, slow members, two cliques, stale other-parents."""
     monkeypatch.setenv("SW_FIN_BAND", fin_band)
+    monkeypatch.setenv("SW_BAND_FAST", band_fast)   # (round 5) full groups of 8 band events through the fixed-index path, or the generic path only
     for n, N, seed, mode, p0, p1, chunk in [(130, 14000, 175, 0, 0, 0, None), (256, 30000, 176, 2, 0.2, 0.05, 7000),
                                             (100, 9000, 177, 1, 0.02, 0, 1500), (200, 20000, 178, 3, 0.6, 0, 333), (40, 8000, 179, 2, 0.5, 0.01, 1)]:
         stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)

@@ -36,6 +36,8 @@ def test_random_shapes(pkg, monkeypatch, seed):
     # (drawn after everything else, so that the shapes of the earlier rounds' sweeps stay what they were) round numbers and
     # sees-masks from the band pass + check (default) or every event from its row
     monkeypatch.setenv("SW_FIN_BAND", str(int(np.random.default_rng(8000 + seed).choice([0, 1, 1]))))
+    # (round 5) the band pass's path for full groups of 8 events (default) or the generic path only
+    monkeypatch.setenv("SW_BAND_FAST", str(int(np.random.default_rng(8100 + seed).choice([0, 1, 1]))))
     stake = None
     if n >= 8 and rng.random() < 0.2:  # near-unit weighted stakes (the only weighted kind that progresses)
         stake = np.ones(n, np.uint64)
