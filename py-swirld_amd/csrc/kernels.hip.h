@@ -49,20 +49,57 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // Wave and workgroup reductions for the resolve step.  LDS atomics on one address with a
 // different value per lane are expanded by the compiler into a 64-trip scalar loop (~2 us on the
 // critical path of every iteration): butterflies + one LDS slot per wave + ONE barrier instead.
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
-    return v;
+// Round 5: the butterflies no longer go through ds_bpermute (`__shfl_xor`: six DEPENDENT trips through the LDS
+// crossbar per reduction, ~0.3 us each time on the critical path of both loop kernels) — four DPP steps inside a
+// row of 16 lanes, then v_permlane16_swap / v_permlane32_swap (gfx950) across the rows: VALU only.
+// EVERY lane of the wave must be active at the call (all call sites are in wave-uniform control flow).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <- lane 7 - i of its 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <- lane 15 - i of its row
+constexpr int DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;   // rotation inside a row of 16 lanes
+
+// the two addends of a butterfly step across rows: {own, partner} up to order, the same pair in both partner lanes
+__device__ __forceinline__ void rows_pair16(int v, int& a, int& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)r[0]; b = (int)r[1];
 }
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
-    return v;
+__device__ __forceinline__ void rows_pair32(int v, int& a, int& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)r[0]; b = (int)r[1];
 }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+#define SW_WAVE_REDUCE(v, OP)                                                                   \
+    do {                                                                                        \
+        int o_, a_, b_;                                                                         \
+        o_ = dpp_i32<DPP_XOR1>(v); v = OP(v, o_);                                               \
+        o_ = dpp_i32<DPP_XOR2>(v); v = OP(v, o_);                                               \
+        o_ = dpp_i32<DPP_HALF_MIRROR>(v); v = OP(v, o_);                                        \
+        o_ = dpp_i32<DPP_MIRROR>(v); v = OP(v, o_);                                             \
+        rows_pair16(v, a_, b_); v = OP(a_, b_);                                                 \
+        rows_pair32(v, a_, b_); v = OP(a_, b_);                                                 \
+    } while (0)
+#define SW_OP_MIN(x, y) ((y) < (x) ? (y) : (x))
+#define SW_OP_MAX(x, y) ((y) > (x) ? (y) : (x))
+#define SW_OP_ADD(x, y) ((x) + (y))
+__device__ __forceinline__ int wave_min_i32(int v) { SW_WAVE_REDUCE(v, SW_OP_MIN); return v; }
+__device__ __forceinline__ int wave_max_i32(int v) { SW_WAVE_REDUCE(v, SW_OP_MAX); return v; }
+__device__ __forceinline__ int wave_sum_i32(int v) { SW_WAVE_REDUCE(v, SW_OP_ADD); return v; }
+
+// the two addends of the bit-sliced adders' step across lane distance OFF (a power of two): lanes (g, w) and (g', w) of one
+// mask word w.  Inside a row the partner comes by DPP — an xor for OFF 1 / 2, a ROTATION for 4 / 8 (the steps are taken in
+// ascending order up to 8, so the rotations by 4 and by 8 together visit every group of the row: each lane ends with the sum
+// over all of them, like the xor butterfly) — across rows by the permlane swaps.
+template <int OFF>
+__device__ __forceinline__ void lanes_pair(uint32_t x, uint32_t& a, uint32_t& b) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "lane distance");
+    if constexpr (OFF == 32) { int a_, b_; rows_pair32((int)x, a_, b_); a = (uint32_t)a_; b = (uint32_t)b_; }
+    else if constexpr (OFF == 16) { int a_, b_; rows_pair16((int)x, a_, b_); a = (uint32_t)a_; b = (uint32_t)b_; }
+    else if constexpr (OFF == 8) { a = x; b = (uint32_t)dpp_i32<DPP_ROR8>((int)x); }
+    else if constexpr (OFF == 4) { a = x; b = (uint32_t)dpp_i32<DPP_ROR4>((int)x); }
+    else if constexpr (OFF == 2) { a = x; b = (uint32_t)dpp_i32<DPP_XOR2>((int)x); }
+    else { a = x; b = (uint32_t)dpp_i32<DPP_XOR1>((int)x); }
 }
 
 
@@ -1040,7 +1077,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
     pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
-    const int nthr = (int)blockDim.x;
+    // workgroups of max(npad, 256) threads (enqueue_iteration): a COMPILE-TIME wave count — with a run-time one the three
+    // reductions below were general loops whose remainder form (4 waves < the unroll factor of 8) read LDS one dependent word
+    // at a time (round 5, from the ISA)
+    constexpr int nthr = NW * 64 < 256 ? 256 : NW * 64;
     // (measured and dropped in round 4, profiles/r04d_*: an extra wave per workgroup that touches the rows of the previous
     // band + one round while the member threads resolve.  The stamped block's band phase went from 3.4 to 2.1 us and the
     // pass did not move: the band phase is bound by the bytes of the whole band, not by the latency of a wave's loads.)
@@ -1048,7 +1088,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     RState* so = B.st + (1 - par);
     const bool writer = blockIdx.x == 0;
     const int c = threadIdx.x;
-    const size_t in = (size_t)par * npad, out = (size_t)(1 - par) * npad;
+    const unsigned in = (unsigned)(par * npad), out = (unsigned)((1 - par) * npad);   // (32-bit offsets: scalar base + vector offset addressing)
     const bool member = (NW >= 4) || c < npad;   // (workgroups of max(npad, 256) threads: every thread is a member from 256 members on)
     // First memory round trip: the loop state and every per-member value whose address does not
     // depend on it, issued together BEFORE the first branch (a load behind an early return cannot
@@ -1096,9 +1136,9 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // saved here, 128.1 -> 126.3 M events/s)
     // (clamped rows, unconditional loads, selects afterwards: see above)
     const int rq1 = r + 1 < Rcap ? r + 1 : Rcap - 1, rq2 = r + 2 < Rcap ? r + 2 : Rcap - 1;
-    const int lo_r1_ld = lo[(size_t)rq1 * npad + cq];
-    const int lo_r2_ld = lo[(size_t)rq2 * npad + cq];
-    const int lopos_r1_ld = lopos[(size_t)rq1 * npad + cq];
+    const int lo_r1_ld = lo[(unsigned)(rq1 * npad + cq)];
+    const int lo_r2_ld = lo[(unsigned)(rq2 * npad + cq)];
+    const int lopos_r1_ld = lopos[(unsigned)(rq1 * npad + cq)];
     const int lo_r1 = (member && r + 1 < Rcap) ? lo_r1_ld : SW_INF;
     const int lo_r2 = (member && r + 2 < Rcap) ? lo_r2_ld : SW_INF;
     const int lopos_r1 = (member && r + 1 < Rcap) ? lopos_r1_ld : 0;
@@ -1211,7 +1251,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             }
         }
     }
-    const int rl = c & 63, rw = c >> 6, nwv = nthr >> 6;
+    const int rl = c & 63, rw = c >> 6;
+    constexpr int nwv = nthr >> 6;
     int nun = 0;
     {   // count(un) and any(grow) with one barrier
         // (round 4, measured and dropped — profiles/r04i_*: the next round's entry counts computed speculatively and reduced on
@@ -1221,6 +1262,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         if (rl == 0) { s_red[0][0][rw] = __popcll(bu); s_red[0][1][rw] = bg != 0; }
         __syncthreads();
         int anyg = 0;
+#pragma unroll
         for (int w = 0; w < nwv; ++w) { nun += s_red[0][0][w]; anyg |= s_red[0][1][w]; }
         if (anyg && ncap < MCAP) ncap = ncap * 2 < MCAP ? ncap * 2 : MCAP;
     }
@@ -1231,8 +1273,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         if (iter > 0) {  // commit round r, then look at round r+1
             if (my_lo_next != SW_INF) {
                 if (writer) {
-                    lo[(size_t)(r + 1) * npad + c] = my_lo_next;
-                    lopos[(size_t)(r + 1) * npad + c] = my_pos_next;
+                    lo[(unsigned)((r + 1) * npad + c)] = my_lo_next;
+                    lopos[(unsigned)((r + 1) * npad + c)] = my_pos_next;
                     B.front[c] = r + 1;
                 }
                 lr = my_lo_next;
@@ -1244,8 +1286,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             nx = lo_r2;
             r = r + 1;
         } else {
-            lr = (member && r < Rcap) ? lo[(size_t)r * npad + c] : SW_INF;
-            start = (member && r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
+            lr = (member && r < Rcap) ? lo[(unsigned)(r * npad + c)] : SW_INF;
+            start = (member && r < Rcap) ? lopos[(unsigned)(r * npad + c)] : 0;
             nx = lo_r1;
         }
         SW_STAMP(stamp && B.dbg_minor, iter, 8);
@@ -1271,6 +1313,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                 if (rl == 0) { s_red[lp][0][rw] = __popcll(ba); s_red[lp][1][rw] = __popcll(bu); s_red[lp][2][rw] = wm; }
                 __syncthreads();
                 nun = 0;
+#pragma unroll
                 for (int w = 0; w < nwv; ++w) {
                     nact += s_red[lp][0][w];
                     nun += s_red[lp][1][w];
@@ -1295,8 +1338,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             }
             ++r;  // nothing to do in this round: step to the next one (rare, incremental calls)
             lr = nx;
-            start = (member && r < Rcap) ? lopos[(size_t)r * npad + c] : 0;
-            nx = (member && r + 1 < Rcap) ? lo[(size_t)(r + 1) * npad + c] : SW_INF;
+            start = (member && r < Rcap) ? lopos[(unsigned)(r * npad + c)] : 0;
+            nx = (member && r + 1 < Rcap) ? lo[(unsigned)((r + 1) * npad + c)] : SW_INF;
         }
     }
     if (done) un = 0;
@@ -1320,6 +1363,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             s_res[c] = strd;
         }
         __syncthreads();
+#pragma unroll
         for (int w = 0; w < nwv; ++w) {
             const int m = s_red[0][3][w];
             s_max = m > s_max ? m : s_max;
@@ -1405,7 +1449,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     if (B.dbg && stamp && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb + 7] = (u64)(need_mask ? mhi - mask_from : 0);
     if (done || !need_mask) { flush_cand(); return; }
     const int lane = lane_id();
-    const int wpb = nthr >> 6;
+    constexpr int wpb = nthr >> 6;
     // the writer block finishes later than the others (it publishes the state): it takes no
     // share of the band, so that the kernel ends with the band and not with its stores
     const int skipw = gridDim.x > 1 ? 1 : 0;
@@ -1776,27 +1820,32 @@ __device__ __forceinline__ void bits_accumulate_z(const int* pk, const uint32_t*
 }
 
 // cross-lane part for bits_accumulate_z: level k adds two counts of PA + k planes
-template <int NW>
-__device__ __forceinline__ uint32_t bits_finish_z(uint32_t (&b)[ilog2_c(64 * NW) + 1], const uint32_t t23) {
-    using Gm = BitsGeom<NW>;
-    constexpr int W32 = Gm::W32, PLT = Gm::PLT;
-    int top = Gm::PA;
-#pragma unroll
-    for (int off = W32; off < 64; off <<= 1) {
+template <int NW, int OFF, int TOP>
+__device__ __forceinline__ void bits_level_z(uint32_t (&b)[ilog2_c(64 * NW) + 1]) {
+    constexpr int PLT = ilog2_c(64 * NW) + 1;
+    if constexpr (OFF < 64) {
         uint32_t carry = 0;
 #pragma unroll
         for (int p = 0; p < PLT; ++p) {
-            if (p < top) {
-                const uint32_t y = (uint32_t)__shfl_xor((int)b[p], off);
-                const uint32_t u = b[p] ^ y;
-                const uint32_t nc = (b[p] & y) | (u & carry);
+            if (p < TOP) {
+                uint32_t x, y;
+                lanes_pair<OFF>(b[p], x, y);
+                const uint32_t u = x ^ y;
+                const uint32_t nc = (x & y) | (u & carry);
                 b[p] = u ^ carry;
                 carry = nc;
             }
         }
-        if (top < PLT) b[top] = carry;
-        ++top;
+        if constexpr (TOP < PLT) b[TOP] = carry;
+        bits_level_z<NW, OFF * 2, TOP + 1>(b);
     }
+}
+
+template <int NW>
+__device__ __forceinline__ uint32_t bits_finish_z(uint32_t (&b)[ilog2_c(64 * NW) + 1], const uint32_t t23) {
+    using Gm = BitsGeom<NW>;
+    constexpr int W32 = Gm::W32, PLT = Gm::PLT;
+    bits_level_z<NW, W32, Gm::PA>(b);
     uint32_t gt = 0, eq = 0xffffffffu;  // most significant plane first
 #pragma unroll
     for (int p = PLT - 1; p >= 0; --p) {
@@ -1811,21 +1860,28 @@ __device__ __forceinline__ uint32_t bits_finish_z(uint32_t (&b)[ilog2_c(64 * NW)
 // part 2: add the G hop groups across lanes (bit-sliced full adders) and compare every
 // member's count with t23 = floor(2T/3); returns, in every lane (g, w), the 32-member word w
 // of "hits > 2T/3".
-template <int NW>
-__device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) + 1], const uint32_t t23) {
-    constexpr int W32 = 2 * NW, PLT = ilog2_c(64 * NW) + 1;
-#pragma unroll
-    for (int off = W32; off < 64; off <<= 1) {
+template <int NW, int OFF>
+__device__ __forceinline__ void bits_level(uint32_t (&b)[ilog2_c(64 * NW) + 1]) {
+    constexpr int PLT = ilog2_c(64 * NW) + 1;
+    if constexpr (OFF < 64) {
         uint32_t carry = 0;
 #pragma unroll
         for (int p = 0; p < PLT; ++p) {
-            const uint32_t y = (uint32_t)__shfl_xor((int)b[p], off);
-            const uint32_t u = b[p] ^ y;
-            const uint32_t nc = (b[p] & y) | (u & carry);
+            uint32_t x, y;
+            lanes_pair<OFF>(b[p], x, y);
+            const uint32_t u = x ^ y;
+            const uint32_t nc = (x & y) | (u & carry);
             b[p] = u ^ carry;
             carry = nc;
         }
+        bits_level<NW, OFF * 2>(b);
     }
+}
+
+template <int NW>
+__device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) + 1], const uint32_t t23) {
+    constexpr int W32 = 2 * NW, PLT = ilog2_c(64 * NW) + 1;
+    bits_level<NW, W32>(b);
     uint32_t gt = 0, eq = 0xffffffffu;  // most significant plane first
 #pragma unroll
     for (int p = PLT - 1; p >= 0; --p) {
@@ -1963,9 +2019,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         }
     }
     const uint32_t gt = bits_finish_z<NW>(b, tot2 / 3u);
-    uint32_t cnt = (g == 0) ? __popc(gt) : 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    const uint32_t cnt = (uint32_t)wave_sum_i32((g == 0) ? __popc(gt) : 0);
     if (3u * cnt > tot2) {  // count of members vs the STAKE threshold (Q2)
         const int dl = ((gsv & 0xff) == 1 && la >= 0 && la - e < 0x3ffffff) ? la - e : 0x3ffffff;
         key = ((u64)(uint32_t)e << 32) | ((u64)cj << 26) | (u64)dl;
@@ -2065,9 +2119,7 @@ __device__ __forceinline__ int tree_eval(const int e, const bool forced, const i
         }
     }
     const uint32_t gt = bits_finish_z<NW>(b, tot2 / 3u);
-    uint32_t cnt = (g == 0) ? __popc(gt) : 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    const uint32_t cnt = (uint32_t)wave_sum_i32((g == 0) ? __popc(gt) : 0);
     return 3u * cnt > tot2 ? 1 : 0;   // count of members vs the STAKE threshold (Q2)
 }
 
@@ -2114,7 +2166,8 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     if (s_done || !un) return;   // (uniform over the workgroup: nobody reaches a barrier)
     const int live = __popcll(__ballot(lane >= 1 && lane <= K && ce_lane >= 0));   // candidates are contiguous from slot 0
     if (live == 0) return;
-    auto slot_ev = [&](int j) -> int { return __shfl(ce_lane, j + 1); };
+    // (every slot index below is uniform over the wave: v_readlane instead of a ds_bpermute round trip in front of the row address)
+    auto slot_ev = [&](int j) -> int { return __builtin_amdgcn_readlane(ce_lane, __builtin_amdgcn_readfirstlane(j + 1)); };
     int* pk = s_pk[wib];
     u64 nfar = 0;
     int evals = 0;
@@ -2137,6 +2190,9 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         // (round 4, measured and dropped — profiles/r04m_*: the rows of a wave's bracket loaded with its probe's row and their hop
         // lists staged in LDS before the barrier, so that level 2 starts at the gathers: level 2 went from 2.4 to 2.0 us, level 1
         // from 2.4 to 3.7 us)
+        // (round 5, measured and dropped — profiles/r05c_ab_256x1M.log: every kernel starts with a cold L2, so the rows of level 2 are a
+        // second trip to memory behind the barrier; each probing wave requesting the rows of its own bracket behind its probe's row
+        // (values unused, 4 x the row traffic) made the pass 0.4 % slower: 6.21 -> 6.235 ms)
         if (wib < nprobe) {
             const int j1 = (wib + 1) * s - 1 < live - 1 ? (wib + 1) * s - 1 : live - 1;
             if (!(frc && j1 == 0)) k1 = tree_eval<NW>(slot_ev(j1), false, cm, mlo, mhi, thr, pk, L, sp, op, Mb32, tot2, npad, lane, nfar);

@@ -461,6 +461,8 @@ int ensure_rounds(sw_ctx* c, int need) {
     if (need <= c->Rcap) return SW_OK;
     int nc = c->Rcap ? c->Rcap : 256;
     while (nc < need) nc *= 2;
+    // (the loop kernels address lo / lopos with 32-bit offsets)
+    if ((int64_t)nc * c->npad >= (1ll << 31)) return fail(c, SW_ERANGE, "round table of %d rounds x %d columns exceeds 2^31 entries", nc, c->npad);
     // the per-round tables move: nothing may still be writing the old ones (the aux stream fills
     // witness rows behind the round loop)
     if (c->stream_aux) HIPCHK(c, hipStreamSynchronize(c->stream_aux));
