@@ -31,6 +31,8 @@ print("%d members, %d events: %d stamped iterations" % (n, N, len(idx)))
 
 
 def q(name, d):
+    if not len(d):
+        return
     d = d / 100.0  # 100 MHz -> us
     print("  %-52s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f us" % (name, d.mean(), *np.percentile(d, [10, 50, 90])))
 
@@ -83,3 +85,17 @@ if slow.any():
                 lab, ((t[i2, T] - t[i2, 6]) / 100.0).mean(), ((t[i2, T + 5] - t[i2, T]) / 100.0).mean(), ((t[i2 + 1, A] - t[i2, T + 5]) / 100.0).mean()))
     print("   iteration index of the slow ones (mod 24):", np.bincount(idx[slow] % 24, minlength=24).tolist())
     print("   first 40 slow iteration indices:", idx[slow][:40].tolist())
+# ---- the same phases along the pass (round 5: the stamps are indexed by the iteration of the context, so the loops of all
+# sub-batches are there): groups of consecutive iterations, to see what the sweeps running beside the first loops cost and where
+G = int(os.environ.get("LOOP_PHASES_GROUP", "24"))
+last = idx[idx >= idx.max() - int(os.environ.get("LOOP_PHASES_LAST", "330"))]
+print(" along the pass (groups of %d iterations; medians, us): period | resolve step | band | resolve end -> tally entry | tally wave | tally end -> next entry" % G)
+for a0 in range(0, len(last), G):
+    g = last[a0:a0 + G]
+    g = g[(t[g, T] > 0) & (t[g, T + 5] > 0) & (t[g, 5] > 0)]
+    if len(g) < 4:
+        continue
+    med = lambda x: float(np.median(x)) / 100.0
+    print("   iterations %5d..%5d: %6.2f | %5.2f | %5.2f | %5.2f | %5.2f | %5.2f" % (
+        g[0], g[-1], med(t[g + 1, A] - t[g, A]), med(t[g, 5] - t[g, 0]), med(t[g, 6] - t[g, 5]), med(t[g, T] - t[g, 6]),
+        med(t[g, T + 5] - t[g, T]), med(t[g + 1, A] - t[g, T + 5])))

@@ -34,7 +34,7 @@ struct RState {
     u64 far_hops;   // hop masks computed on the fly (outside the band)
     u64 band_events;  // band events whose threshold mask was (re)built (work of k_resolve_band's step 2)
     int fin_from;     // first event of THIS run's sub-batch: band events from here on get their round and sees-mask from the band pass
-    int pad_;
+    int pad_;         // diagnostics (SW_DEBUG_CLOCKS): iterations of the context before this loop — the index base of the phase stamps
 };
 
 struct FameCounters {
@@ -580,7 +580,10 @@ __device__ __forceinline__ void load_cols_sc1_and_wait(const int* ptr, int (&v)[
 template <int C>
 __device__ __forceinline__ void store_cols(int* ptr, const int (&v)[C]) {
     // (round 5, measured and dropped — profiles/r05a_knobs_256x1M.log: streaming (`nt`) stores for the rows, to keep the sweep out of
-    // the L2 the round loop gathers from: 7.00 -> 7.78 ms per pass — the rows of one chain are assembled in L2 from 16-byte pieces)
+    // the L2 the round loop gathers from: 7.00 -> 7.78 ms per pass — the rows of one chain are assembled in L2 from 16-byte pieces;
+    // profiles/r05i_*, r05k_*: write-through (`sc0 sc1`) stores, so that the loop's kernel boundaries find no dirty lines of the
+    // sweep to write back: the sweeps end ~25 iterations earlier, the iterations beside them take 26-27 us instead of 20.5 —
+    // boundaries AND kernels: 6.14 -> 6.42 ms.  What the sweep costs the loop beside it is its memory traffic, whatever its form.)
     if constexpr (C == 4) *reinterpret_cast<int4*>(ptr) = make_int4(v[0], v[1], v[2], v[3]);
     else *reinterpret_cast<int2*>(ptr) = make_int2(v[0], v[1]);
 }
@@ -1030,8 +1033,34 @@ __device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v));
 
 // Start of a round-loop run: the loop state and the per-member buffers in ONE launch (a small
 // call would otherwise pay five separate copies / fills, ~10 us each).
+// CHAINED start (round 5): the loop of the next sub-batch is enqueued right behind the shot of the running one, without the host
+// round trip in between (read the state, find the start round, launch).  What the host computed then is found here: the previous
+// loop must have reported `done` (an even number of launches leaves its final state in half 0) — if not, this launch REFUSES:
+// it touches nothing, the iterations enqueued behind it go on with the old loop, and the host (which sees the same state in its
+// read-back) starts this loop again the slow way; the exhaustion marks are in the half the previous loop's iteration count
+// names; the start round is the smallest front round among the members this sub-batch adds events to (their visible chain
+// grows), else the last round.  A sub-batch that holds a member's first event is never chained (its root row comes from the host).
 __global__ void __launch_bounds__(1024)
-k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len, int eval_src, int fin_from) {
+k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len, int eval_src, int fin_from,
+            int chained, int prev_N) {
+    __shared__ int s_min[16];
+    if (chained) {
+        const RState* pv = B.st;
+        if (!pv->done || pv->err || pv->N != prev_N) return;   // refused (uniform over the workgroup)
+        eval_src = pv->iter & 1;
+        const int last_round = pv->max_round > 0 ? pv->max_round : 0;
+        int mine = SW_INF;
+        for (int i = threadIdx.x; i < npad; i += blockDim.x)
+            if (visible_len[i] > chain_len[i]) { const int f = B.front[i]; mine = f < mine ? f : mine; }
+        mine = wave_min_i32(mine);
+        if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        r_start = SW_INF;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r_start = s_min[w] < r_start ? s_min[w] : r_start;
+        if (r_start == SW_INF) r_start = last_round;
+        if (r_start < 0) r_start = 0;
+        __syncthreads();   // (everybody has read the old chain lengths and the old state)
+    }
     // chain lengths visible to this run = the sub-batch's row of the cut table (already on the device)
     for (int i = threadIdx.x; i < npad; i += blockDim.x) { chain_len[i] = visible_len[i]; B.treecnt[i] = 0; }
     if (eval_src)   // the previous run ended on an odd iteration: its exhaustion marks are in half 1, this run reads half 0
@@ -1042,6 +1071,7 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
         t.N = N;
         t.ncap = ncap;
         t.fin_from = fin_from;
+        t.pad_ = B.dbg ? B.st[0].pad_ + B.st[0].iter : 0;   // (diagnostics only: iterations of this context before this loop)
         B.st[0] = t;
     }
     for (int i = threadIdx.x; i < 2 * npad; i += blockDim.x) {
@@ -1064,7 +1094,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
                const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb,
-               int* __restrict__ round_out, u64* __restrict__ S_out) {
+               int* __restrict__ round_out, u64* __restrict__ S_out, int* __restrict__ Pc) {
     __shared__ int s_red[2][4][16];  // [parity][quantity][wave]: per-wave partial results
     __shared__ int s_thr[1024];
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
@@ -1076,7 +1106,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     pin_arg(B.evalround); pin_arg(B.evalpos); pin_arg(B.found64); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg);
     pin_arg(par); pin_arg(npad); pin_arg(K); pin_arg(skip); pin_arg(NEARCAP); pin_arg(MCAP); pin_arg(Rcap);
     pin_arg(chain_start); pin_arg(chain_len); pin_arg(chain_ev); pin_arg(lo); pin_arg(lopos);
-    pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
+    pin_arg(L); pin_arg(cr); pin_arg(op); pin_arg(Mb); pin_arg(Pc); pin_arg((int)blockDim.x); pin_arg((int)gridDim.x);
     // workgroups of max(npad, 256) threads (enqueue_iteration): a COMPILE-TIME wave count — with a run-time one the three
     // reductions below were general loops whose remainder form (4 waves < the unroll factor of 8) read LDS one dependent word
     // at a time (round 5, from the ISA)
@@ -1101,6 +1131,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     const int N = si->N;
     const int s_mlo = si->mlo, s_mhi = si->mhi, s_ncap = si->ncap;
     const int fin_from = si->fin_from;
+    const int dbg_it = iter + si->pad_;   // (diagnostics: stamps are indexed by the iteration of the CONTEXT — the loops of a call's sub-batches one behind the other)
     const int cq = member ? c : 0;
     const int cs = chain_start[cq];
     const int clen_ld = chain_len[cq];  // events of member c visible to this run
@@ -1125,8 +1156,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     int thr = member ? thr_ld : SW_INF;
     const bool stamp = c == 0 && blockIdx.x == 1;  // a block that does not publish the state
     const int sb = 0;
-    if (B.dbg && stamp && !s_done && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb] = wall_clock64();
-    SW_STAMP(stamp && !s_done, iter, sb + 1);
+    if (B.dbg && stamp && !s_done && dbg_it < SW_DBG_MAX_ITERS) B.dbg[(size_t)dbg_it * 32 + sb] = wall_clock64();
+    SW_STAMP(stamp && !s_done, dbg_it, sb + 1);
     if (s_done) {
         if (writer && c == 0) *so = *si;
         return;
@@ -1226,7 +1257,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // lies before that creator's cursor; otherwise c waits for the next iteration.  When both
     // parents have round <= r the candidate needs a real tally: the band cap is doubled.
     int grow = 0;
-    SW_STAMP(stamp && B.dbg_minor, iter, sb + 2);
+    SW_STAMP(stamp && B.dbg_minor, dbg_it, sb + 2);
     if (iter > 0) {
         if (member) {
             // a member is "resolved for round r" unless it is still searching
@@ -1266,7 +1297,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         for (int w = 0; w < nwv; ++w) { nun += s_red[0][0][w]; anyg |= s_red[0][1][w]; }
         if (anyg && ncap < MCAP) ncap = ncap * 2 < MCAP ? ncap * 2 : MCAP;
     }
-    SW_STAMP(stamp && B.dbg_minor, iter, sb + 3);
+    SW_STAMP(stamp && B.dbg_minor, dbg_it, sb + 3);
     int need_mask = 0, done = 0, err = 0, max_round = 0;
     if (nun == 0) {
         int lr, nx, start;
@@ -1290,7 +1321,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             start = (member && r < Rcap) ? lopos[(unsigned)(r * npad + c)] : 0;
             nx = lo_r1;
         }
-        SW_STAMP(stamp && B.dbg_minor, iter, 8);
+        SW_STAMP(stamp && B.dbg_minor, dbg_it, 8);
         int lp = 1;  // s_red[0] was used by the count above
         for (;;) {  // enter the next round that has unresolved members
             if (r + 1 >= Rcap) { err = 1; done = 1; break; }
@@ -1322,10 +1353,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                 }
                 lp ^= 1;
             }
-            SW_STAMP(stamp && B.dbg_minor, iter, 10);
+            SW_STAMP(stamp && B.dbg_minor, dbg_it, 10);
             if (nact == 0) { done = 1; max_round = r - 1; break; }
             if (nun > 0) {
-                SW_STAMP(stamp && B.dbg_minor, iter, 11);
+                SW_STAMP(stamp && B.dbg_minor, dbg_it, 11);
                 mlo = minlr;
                 thr = lr;
                 my_lo_next = SW_INF;
@@ -1343,12 +1374,12 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         }
     }
     if (done) un = 0;
-    SW_STAMP(stamp && B.dbg_minor, iter, sb + 4);
+    SW_STAMP(stamp && B.dbg_minor, dbg_it, sb + 4);
     // candidates of member c in the next tally launch: chain positions [curc, curc + K)
     const int live = !un ? 0 : strd == 1 ? (clen - curc < K ? clen - curc : K)
                                          : ((clen - 1 - curc) / strd + 1 < K ? (clen - 1 - curc) / strd + 1 : K);
     const int maxc = !live ? -1 : (curc == spec_cur && strd == 1 ? spec_last : chain_ev[cs + curc + (live - 1) * strd]);
-    SW_STAMP(stamp && B.dbg_minor, iter, 12);
+    SW_STAMP(stamp && B.dbg_minor, dbg_it, 12);
     int s_max = -1, s_cnt = 0;
     {   // max(last candidate), sum(evaluated) and the thresholds for the band, one barrier
         // (the [.][3] slots are written only here, once per launch)
@@ -1370,7 +1401,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             s_cnt += s_red[1][3][w];
         }
     }
-    SW_STAMP(stamp && B.dbg_minor, iter, 13);
+    SW_STAMP(stamp && B.dbg_minor, dbg_it, 13);
     // Candidate table for the tally (saves it a dependent round trip): workgroup b publishes the
     // window of member b.  The load is issued here and the store deferred behind the band rows, so
     // that it costs this kernel no round trip of its own.
@@ -1395,10 +1426,10 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     }
     auto flush_cand = [&]() {
         if (cand_mine) B.cand[((size_t)(1 - par) * npad + blockIdx.x) * 64 + threadIdx.x] = cand_v;
-        if (B.dbg_blk && iter < SW_DBG_MAX_ITERS) {   // (diagnostics: when this workgroup was done)
+        if (B.dbg_blk && dbg_it < SW_DBG_MAX_ITERS) {   // (diagnostics: when this workgroup was done)
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (threadIdx.x == 0 && blockIdx.x < 2048) B.dbg_blk[((size_t)iter * 2 + 0) * 2048 + blockIdx.x] = wall_clock64();
+            if (threadIdx.x == 0 && blockIdx.x < 2048) B.dbg_blk[((size_t)dbg_it * 2 + 0) * 2048 + blockIdx.x] = wall_clock64();
         }
     };
     // band = every event a candidate can have as a hop: [mlo, max candidate], capped at MCAP
@@ -1416,7 +1447,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             need_mask = 1;
         }
     }
-    SW_STAMP(stamp && B.dbg_minor, iter, 14);
+    SW_STAMP(stamp && B.dbg_minor, dbg_it, 14);
     if (writer) {
         if (member) {
             B.unres[out + c] = un;
@@ -1445,8 +1476,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         }
     }
     // ---- band masks
-    SW_STAMP(stamp, iter, sb + 5);
-    if (B.dbg && stamp && iter < SW_DBG_MAX_ITERS) B.dbg[(size_t)iter * 32 + sb + 7] = (u64)(need_mask ? mhi - mask_from : 0);
+    SW_STAMP(stamp, dbg_it, sb + 5);
+    if (B.dbg && stamp && dbg_it < SW_DBG_MAX_ITERS) B.dbg[(size_t)dbg_it * 32 + sb + 7] = (u64)(need_mask ? mhi - mask_from : 0);
     if (done || !need_mask) { flush_cand(); return; }
     const int lane = lane_id();
     constexpr int wpb = nthr >> 6;
@@ -1465,8 +1496,8 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // (half the bytes: 8.34 ms with ushort loads, 8.77 ms with vector loads) — four dword loads per row it stays.
     const int g_first = mask_from >> 3;
     for (int g = g_first + ((wave - g_first) % nwaves + nwaves) % nwaves; g * 8 < mhi; g += nwaves) {
-        // (masks are built for every band event: testing "can it be a hop at all" first would
-        // cost a dependent load, an unused mask costs 1 KB of row traffic)
+        // (up to 256 members masks are built for every band event: testing "can it be a hop at all" first costs a dependent load in
+        // a latency-bound phase, an unused mask 1 KB of row traffic.  Beyond — SKIP below — the phase is bound by the bytes of the rows.)
         const int base = g * 8;
         const int kk = base + (lane & 7);
         const bool mine = lane < 8 && kk < mhi && kk >= mask_from;
@@ -1487,6 +1518,18 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             return __ballot(mine && kk >= fin_thr && kk >= fin_from);
         };
         constexpr int RIF = NW <= 4 ? 8 : 4;  // rows in flight per wave (one memory round trip per pass)
+        // SKIP (round 5, 512 members and more): a band event BELOW its creator's threshold lo[r][creator] has round < r — no candidate
+        // counts it as a hop (a hop is an entry >= lo[r][its column], the tally's `valid`), nothing reads its mask, and its round and
+        // sees-mask are not this pass's to write.  Its row (4 KB at 1024 members) is not fetched: one dependent look-up in a phase
+        // that moves 146 MB per iteration.
+        constexpr bool SKIP = NW >= 8;
+        u64 fin_pre = 0;
+        if constexpr (SKIP) {
+            asm volatile("" : "+v"(crk));
+            const int thr_c = s_thr[crk];
+            vm = __ballot(mine && kk >= thr_c);
+            fin_pre = __ballot(mine && kk >= thr_c && kk >= fin_from);
+        }
         if constexpr (FAST && RIF == 8) {
             // a FULL group — eight consecutive events, all of them band events (the common case): fixed indices, ONE 64-bit
             // row base per group and compile-time offsets (npad = 64 NW) instead of the ffs / mask bookkeeping and a
@@ -1502,15 +1545,19 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                 const u64 fin_m = fin_mask();
                 u64* mb0 = Mb + (size_t)(base - mlo) * NW + lane;
                 u64* s0 = S_out + (size_t)base * NW + lane;
+                int* pc0 = Pc + (base - mlo);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     u64 word = 0;
+                    int pcs = 0;   // popcount of the whole mask: the tally's cheap bounds (k_tally_bits, FILT) add these up
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
                         const u64 bm = __ballot(v[u][j] >= t_[j]);
                         word = lane == j ? bm : word;
+                        pcs += __popcll(bm);
                     }
                     if (lane < NW) mb0[u * NW] = word;
+                    if (lane == NW + 1) pc0[u] = pcs;
                     if ((fin_m >> u) & 1ull) {
                         if (lane < NW) s0[u * NW] = word;
                         if (lane == NW) round_out[base + u] = r;
@@ -1532,17 +1579,20 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
                     v[u][j] = ks[u] >= 0 ? L[(size_t)ks[u] * npad + j * 64 + lane] : -1;
-                const u64 fin_m = fin_mask();   // (RIF covers a whole group: this loop makes one pass)
+                const u64 fin_m = SKIP ? fin_pre : fin_mask();   // (up to 256 members RIF covers a whole group: this loop makes one pass)
 #pragma unroll
             for (int u = 0; u < RIF; ++u)
                 if (ks[u] >= 0) {
                     u64 word = 0;   // lane j < NW keeps mask word j: the NW words of an event leave in ONE store instruction
+                    int pcs = 0;
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
                         const u64 bm = __ballot(v[u][j] >= t_[j]);
                         word = lane == j ? bm : word;
+                        pcs += __popcll(bm);
                     }
                     if (lane < NW) Mb[(size_t)(ks[u] - mlo) * NW + lane] = word;
+                    if (lane == NW + 1) Pc[ks[u] - mlo] = pcs;
                     if ((fin_m >> (ks[u] - base)) & 1ull) {
                         if (lane < NW) S_out[(size_t)ks[u] * NW + lane] = word;
                         if (lane == NW) round_out[ks[u]] = r;
@@ -1551,7 +1601,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         }
     }
     flush_cand();
-    SW_STAMP(stamp, iter, sb + 6);
+    SW_STAMP(stamp, dbg_it, sb + 6);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1895,13 +1945,19 @@ __device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) +
 
 // (round 5, measured and dropped — profiles/r05a_knobs_1024x2M.log: at 1024 members the kernel takes 99 VGPRs = 4 waves per SIMD; asking
 // the allocator for 5 waves (96 VGPRs, 8 B of scratch) changes nothing, for 6 (80 VGPRs, 18 spilled dwords) costs 6 %)
-template <int NW>
+// FILT (round 5): before the n masks of a candidate are gathered, the POPCOUNTS of those masks (Pc[], left by the band pass: 4 bytes
+// per hop instead of n / 8) bound the verdict from both sides.  With V valid hops, t = floor(2T/3) and S = sum of the hops'
+// popcounts = sum over the columns of hits[c_]:  a passing tally has more than t columns with hits > t, hence S >= (t + 1)^2 —
+// below that the candidate FAILS without a gather; a failing one has at most t columns above t, each at most V, the others at
+// most t, hence S <= t V + (n - t) t — above that it PASSES without a gather.  On uniform gossip the two bounds leave ~4 of a
+// member's slots for the exact count (tests/model_bulk.py `popcount_bounds`); every verdict is still exact.
+template <int NW, bool FILT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 4 ? 8 : 2, 8)))
 k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
              const int* __restrict__ chain_ev,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-             const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
+             const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad, const int* __restrict__ Pc) {
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
     constexpr int G = 64 / W32;          // hop groups
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
@@ -1962,7 +2018,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     // stamped waves: candidate slot K/2 of the first and of the last member
     const bool stamp = B.dbg && lane == 0 && cj == (K >> 1) && (cm == 0 || cm == (int)(gridDim.x * 4 / K) - 1);
     const int sb = cm == 0 ? 16 : 24;
-    const int it_ = stamp ? st->iter - 1 : 0;
+    const int it_ = stamp ? st->iter - 1 + st->pad_ : 0;
     if (stamp && !s_done && it_ < SW_DBG_MAX_ITERS) B.dbg[(size_t)it_ * 32 + sb] = wall_clock64();
     SW_STAMP(stamp && !s_done, it_, sb + 1);
     if (s_done) return;   // (uniform over the grid: no wave of this workgroup reaches the barrier below)
@@ -1978,6 +2034,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     if ((spe > ope ? spe : ope) >= mhi && !(cj == 0 && frc)) { fark = cj; break; }
     u64 farm[NW];
     uint32_t nvalid = 0;
+    int prow[NW];   // this lane's hops as rows of the band tables (0: not a hop)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         int v = P[j];
@@ -1985,7 +2042,8 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         P[j] = v;
         const bool valid = v >= thr[j];
         const bool inband = valid && v < mhi;
-        pk[Gm::slot(j * 64 + lane)] = inband ? v - mlo + 1 : 0;  // row 0 of the table is all-zero
+        prow[j] = inband ? v - mlo + 1 : 0;  // row 0 of the table is all-zero
+        pk[Gm::slot(j * 64 + lane)] = prow[j];
         farm[j] = __ballot(valid && !inband);
         nfar += __popcll(farm[j]);
         nvalid += __popcll(__ballot(valid));
@@ -1993,9 +2051,23 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     // necessary condition: a member is strongly seen only through more than 2T/3 (unit-stake)
     // hops, so with fewer valid hops no column can pass — skip the gathers altogether
     if (3u * nvalid <= tot2) break;
+    bool sure = false;
+    if constexpr (FILT) {
+        if (!nfar) {   // (a hop beyond the band has no popcount in the table: the exact count decides)
+            int sum = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) sum += Pc[prow[j]];
+            const uint32_t S = (uint32_t)wave_sum_i32(sum);
+            const uint32_t t = tot2 / 3u, nmem = tot2 >> 1;
+            if (S < (t + 1u) * (t + 1u)) break;                   // fewer hits than t + 1 columns above t need
+            sure = S > t * nvalid + (nmem - t) * t;               // more hits than t columns at V and the rest at t hold
+        }
+    }
+    const int w = lane % W32, g = lane / W32;
+    uint32_t cnt = tot2;   // (a sure pass: any count above 2T/3)
+    if (!sure) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int w = lane % W32, g = lane / W32;
     uint32_t b[PLT];
     bits_accumulate_z<NW>(pk, Mb32, b, lane);
     SW_STAMP(stamp, it_, sb + 4);
@@ -2019,7 +2091,8 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         }
     }
     const uint32_t gt = bits_finish_z<NW>(b, tot2 / 3u);
-    const uint32_t cnt = (uint32_t)wave_sum_i32((g == 0) ? __popc(gt) : 0);
+    cnt = (uint32_t)wave_sum_i32((g == 0) ? __popc(gt) : 0);
+    }
     if (3u * cnt > tot2) {  // count of members vs the STAKE threshold (Q2)
         const int dl = ((gsv & 0xff) == 1 && la >= 0 && la - e < 0x3ffffff) ? la - e : 0x3ffffff;
         key = ((u64)(uint32_t)e << 32) | ((u64)cj << 26) | (u64)dl;
@@ -2041,7 +2114,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     asm volatile("" ::"v"(pf_dummy));   // (the touch's destination register stays reserved to the end)
     SW_STAMP(stamp, it_, sb + 5);
     if (B.dbg_blk) {   // (diagnostics: when this workgroup was done)
-        const int itb = st->iter - 1;
+        const int itb = st->iter - 1 + st->pad_;
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (threadIdx.x == 0 && blockIdx.x < 2048 && itb >= 0 && itb < SW_DBG_MAX_ITERS) B.dbg_blk[((size_t)itb * 2 + 1) * 2048 + blockIdx.x] = wall_clock64();
@@ -2130,7 +2203,8 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
              const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad) {
     using Gm = BitsGeom<NW>;
     __shared__ __attribute__((aligned(16))) int s_pk[8][Gm::PK_INTS];
-    __shared__ int s_k1[8], s_k2[8];
+    __shared__ __attribute__((aligned(16))) int s_k1[8];
+    __shared__ __attribute__((aligned(16))) int s_k2[8];
     __builtin_amdgcn_s_setprio(3);  // critical path: win issue arbitration against the can_see sweep
     pin_arg(B.st); pin_arg(B.lo_r); pin_arg(B.unres); pin_arg(B.farslot); pin_arg(B.force); pin_arg(B.dbg); pin_arg(B.cand);
     pin_arg(B.found64); pin_arg(B.gallop); pin_arg(B.treecnt); pin_arg(par); pin_arg(K); pin_arg(skip); pin_arg(mb_prefetch);
@@ -2160,7 +2234,7 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     }
     const bool stamp = B.dbg && lane == 0 && wib == 0 && (cm == 0 || cm == (int)gridDim.x - 1);
     const int sb = cm == 0 ? 16 : 24;
-    const int it_ = stamp ? st->iter - 1 : 0;
+    const int it_ = stamp ? st->iter - 1 + st->pad_ : 0;
     if (stamp && !s_done && it_ < SW_DBG_MAX_ITERS) B.dbg[(size_t)it_ * 32 + sb] = wall_clock64();
     SW_STAMP(stamp && !s_done, it_, sb + 1);
     if (s_done || !un) return;   // (uniform over the workgroup: nobody reaches a barrier)
@@ -2201,8 +2275,11 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         __syncthreads();
         SW_STAMP(stamp, it_, sb + 3);
         int qw = -1;
+        int k1v[8];   // (all eight words in two wide LDS reads, THEN the selection: a conditional read per word is a dependent trip each)
 #pragma unroll
-        for (int w2 = 7; w2 >= 0; --w2) if (w2 < nprobe && s_k1[w2] != 0) qw = w2;
+        for (int w2 = 0; w2 < 8; ++w2) k1v[w2] = s_k1[w2];
+#pragma unroll
+        for (int w2 = 7; w2 >= 0; --w2) if (w2 < nprobe && k1v[w2] != 0) qw = w2;
         evals += nprobe;
         if (qw >= 0) {
             const int prev = qw * s - 1;
@@ -2213,9 +2290,15 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
                 k2 = tree_eval<NW>(slot_ev(prev + 1 + wib), false, cm, mlo, mhi, thr, pk, L, sp, op, Mb32, tot2, npad, lane, nfar);
             if (lane == 0) s_k2[wib] = k2;
             __syncthreads();
-            p = q; kind = s_k1[qw];
+            p = q;
+            kind = 0;
 #pragma unroll
-            for (int i = 7; i >= 0; --i) if (i < cnt2 && s_k2[i] != 0) { p = prev + 1 + i; kind = s_k2[i]; }
+            for (int w2 = 0; w2 < 8; ++w2) kind = w2 == qw ? k1v[w2] : kind;
+            int k2v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) k2v[i] = s_k2[i];
+#pragma unroll
+            for (int i = 7; i >= 0; --i) if (i < cnt2 && k2v[i] != 0) { p = prev + 1 + i; kind = k2v[i]; }
             evals += cnt2;
         }
     }
@@ -2234,7 +2317,7 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
         } else if (kind == 2) {
             B.farslot[pb + cm] = p;
         }
-        B.treecnt[cm] += evals;
+        atomicAdd(&B.treecnt[cm], evals);   // (no return value: the read-modify-write does not hold the kernel's end for a round trip)
     }
     if (lane == 0 && nfar) atomicAdd(&st->far_hops, nfar);
     asm volatile("" ::"v"(pf_dummy));   // (the touch's destination register stays reserved to the end)
@@ -2618,6 +2701,7 @@ k_elections_tiled(const int* __restrict__ wit, const u64* __restrict__ Sw, const
     __shared__ int s_wv[64 * NW];
     __shared__ int s_half[64 * NW];   // ceil(tot / 2) of the voter
     __shared__ int s_lot[64 * NW];    // tot - thr3 (signed)
+    __shared__ int4 s_vt[(STAGE && UNIT) ? 64 * NW : 1];   // {witness, ceil(tot / 2), tot - thr3, 0} of the voter: ONE read per voter in the branch-free loop
     __shared__ u64 s_m[STAGE ? 64 * NW * NW : 1];
     __shared__ u64 s_V[NW][CG];
     __shared__ uint32_t s_key[NW][CG];
@@ -2661,12 +2745,39 @@ k_elections_tiled(const int* __restrict__ wit, const u64* __restrict__ Sw, const
                 }
                 s_half[i] = (int)((tot + 1u) >> 1);
                 s_lot[i] = (int)tot - (int)thr3;
+                if constexpr (STAGE && UNIT) s_vt[i] = make_int4(s_wv[i], (int)((tot + 1u) >> 1), (int)tot - (int)thr3, 0);
             }
             __syncthreads();
         }
         u64 acc = 0;
         uint32_t key = 0xffffffffu;
         int nv = 0;
+        if (STAGE && UNIT && d >= 2 && !coin_round) {
+            // the bulk of the work — an ordinary round at distance >= 2, unit stakes — BRANCH-FREE and eight voters at a time (round 5,
+            // from the ISA: the general loop below is one voter per trip with three dependent LDS round trips and a dozen branches
+            // in it; the kernel was bound by those latencies, not by its and-popcounts).  A member without a witness in the voters'
+            // round is masked out instead of skipped: its bit stays 0, its key stays "none", it is not counted.
+            for (int c0 = 0; c0 < 64; c0 += 8) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = j * 64 + c0 + u;
+                    const int4 vt = s_vt[c];
+                    const u64* m = s_m + c * NW;
+                    uint32_t yes = 0;
+#pragma unroll
+                    for (int jj = 0; jj < NW; ++jj) yes += __popcll(m[jj] & V[jj]);
+                    const uint32_t valid = vt.x >= 0 ? 1u : 0u;
+                    const uint32_t v = yes >= (uint32_t)vt.y ? 1u : 0u;                    // majority(): tie -> True (swirld.py:24-27)
+                    const bool sm = (yes >= thr3) | ((int)yes <= vt.z);                    // the winning side holds more than 2/3 of the stake
+                    const uint32_t k = (valid & (uint32_t)sm) ? (((uint32_t)vt.x << 1) | v) : 0xffffffffu;
+                    key = k < key ? k : key;
+                    bits |= (valid & v) << u;
+                    nv += (int)valid;
+                }
+                acc |= (u64)bits << c0;
+            }
+        } else
         for (int ci = 0; ci < 64; ++ci) {
             const int c = j * 64 + ci;
             const int wv = s_wv[c];  // uniform in the wave
@@ -3262,6 +3373,14 @@ k_sync_diff(const int* __restrict__ L, const int* __restrict__ ht, const int* __
 
 // sw_rewind: every table of the voting state back to its initial value in ONE launch (eleven fills and memsets took
 // ~0.1 ms of every measured pass): blockIdx.y = the table, 32-bit words, grid-stride.
+// decide_fame: the new_c flags and the round-level agreement words of the elections, zeroed in ONE launch (two memsets were
+// three fill kernels of ~5 us each in front of the elections, at the end of every pass)
+__global__ void __launch_bounds__(256)
+k_fame_prep(unsigned char* newc, int R, int* rsc, int n_rsc) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) newc[i] = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rsc; i += gridDim.x * blockDim.x) rsc[i] = 0;
+}
+
 struct RewindJob { int* p[12]; unsigned long long n[12]; int v[12]; };
 __global__ void k_rewind_fill(RewindJob J) {
     int* p = J.p[blockIdx.y];

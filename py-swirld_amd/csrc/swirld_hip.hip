@@ -76,7 +76,7 @@ struct sw_ctx {
     hipStream_t stream_aux = nullptr;  // per-sub-batch finalize + voter masks run here, behind the round loop
     FameCounters fc_seen{};            // device fame counters already added to ctr
     std::vector<hipEvent_t> cs_events;
-    int pipe = 4;                       // sub-batches per divide_rounds call (pipelining depth)
+    int pipe = 5;                       // sub-batches per divide_rounds call behind the short first one (pipelining depth)
     std::string err;
 
     // host mirror of the DAG (validation, height, chains)
@@ -119,7 +119,7 @@ struct sw_ctx {
     int chunks = 4;               // SW_CHUNKS: chunks swept concurrently per sub-batch (1 = the unchunked k_cansee_flow)
     int chunk_cfg = 0;            // SW_CHUNK_CFG: 0 = 4 columns per lane, FIFO 8, ring 8; 1 = 2 columns, 8 / 16; 2 = 4 columns, 4 / 8
     int64_t halo = 0;             // SW_HALO: events recomputed in front of a chunk (default 32 x npad: ~2.4x the age of a row's oldest entry at uniform gossip)
-    int64_t chunk_min = 16384;    // SW_CHUNK_MIN: smallest chunk worth a halo
+    int64_t chunk_min = 8192;     // SW_CHUNK_MIN: smallest chunk worth a halo (round 5: 16384 -> 8192, the short first sub-batch — the one sweep nothing hides — goes out as 4 chunks instead of 3: 6.03 -> 5.98 ms, profiles/r05n_knobs_256x1M.log)
     bool chunks_off = false;      // set when a call had to sweep chunks twice (members silent for longer than the halo): unchunked from then on
     struct ChunkPlan { int G = 0; int row0 = 0; int64_t a[SW_MAX_CHUNKS + 1]; int64_t w[SW_MAX_CHUNKS]; };
     std::vector<ChunkPlan> chunk_plan;   // per sub-batch of the running call
@@ -172,12 +172,21 @@ struct sw_ctx {
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
+    DBuf<int32_t> d_Pc;    // [MCAP + 1] popcounts of the band masks (row 0 = 0, like d_Mb): the cheap bounds of k_tally_bits<., FILT>
     DBuf<int32_t> d_rsc;   // [R][3] round-level agreement of k_elections_tiled: open witnesses, decided flag, arrival ticket
     DBuf<u64> d_found64;   // [2][npad] {event << 32 | slot << 26 | look-ahead} of the members' first passing candidates (LoopBufs::found64)
     // one device block read back with ONE copy per round-loop shot: loop state (x2), sweep error flag, per-member
     // front rounds; and its pinned host mirror
     unsigned char* d_rb = nullptr;
-    unsigned char* h_rb = nullptr;
+    unsigned char* h_rb = nullptr;        // the read-back slot that was read last (one of h_rb_all's)
+    unsigned char* h_rb_all = nullptr;    // SW_PROV_ROWS pinned slots: the loops of a call's sub-batches are read back one behind the other
+    std::vector<hipEvent_t> rb_events, shot_events;   // per slot: read-back complete / last iteration enqueued so far
+    int shot_pct = 100, shot_extra = 2;   // SW_SHOT_PCT / SW_SHOT_EXTRA: a loop's first shot = predicted iterations x pct / 100 + extra (tests: 50 makes every loop top up)
+    int chain = 0;                        // SW_CHAIN: the loop of sub-batch i + 1 is enqueued behind the shot of loop i (k_loop_init, chained start).
+                                          // Off by default (round 5, profiles/r05f_*, r05i_*): with an exact prediction of the iterations it
+                                          // saves ~13 of the ~40 us between two loops (6.08 -> 6.06 ms per pass at 256 members / 1 M events);
+                                          // a shot that falls ONE iteration short makes the chained start refuse and the next loop's whole shot
+                                          // run as no-ops (SW_SHOT_EXTRA=1: 6.5 ms, 0: 7.1 ms) — the loop-by-loop path pays one host round trip
     size_t rb_bytes = 0;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;   // header of d_newc: the fame counters travel with the new_c flags in one copy
@@ -215,6 +224,10 @@ struct sw_ctx {
     int fin_band = 1;      // SW_FIN_BAND: round[] and the sees-masks come from the round loop's band pass, the finalize launch only checks (1) / every event from its row (0)
     int band_fast = 1;     // SW_BAND_FAST: k_resolve_band takes full groups of 8 band events through a path with fixed indices and compile-time offsets
                            // (round 5, profiles/r05a_*: band phase 2.66 -> 1.90 us, 7.00 -> 6.72 ms per pass at 256 members / 1 M events; 0 = the generic path only)
+    int tally_filter = 0;  // SW_TALLY_FILTER: the one-wave-per-slot tally bounds a verdict by the popcounts of the hop masks before it gathers the masks
+                           // (round 5, profiles/r05e_*: default beyond 256 members, where the tally is bound by the bytes it gathers — 1024 members / 2 M
+                           // events 34.8 -> 32.7 ms, 57.4 -> 61.2 M events/s; at 256 members the one-wave-per-slot kernel is bound by its 8 192 wave launches,
+                           // with or without the gathers: 6.58 -> 6.34 ms, the two-level search 6.08)
     int tally_pf = 1;      // SW_TALLY_PF: the first waves of every XCD touch the band-mask table at the head of k_tally_bits (+1 %)
 
     // round-loop graph
@@ -827,7 +840,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
         hipLaunchKernelGGL(kern, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                            c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                            (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p);
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1);
     };
     if constexpr (NW <= 4) {
         if (c->band_fast) resolve_band(k_resolve_band<NW, true>);
@@ -844,9 +857,10 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
             hipLaunchKernelGGL(kern, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, c->tally_pf,
                                (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                                (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                               (const uint32_t*)c->d_Mb.p, tot2, np);
+                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p);
         };
-        tally_bits(k_tally_bits<NW>);
+        if (c->tally_filter) tally_bits(k_tally_bits<NW, true>);
+        else tally_bits(k_tally_bits<NW, false>);
     }
     else if (c->unit_stake)
         hipLaunchKernelGGL((k_tally_candidates<NW, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K,
@@ -879,7 +893,7 @@ int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, st
     key.Rcap = c->Rcap; key.N = c->N; key.lo = (void*)c->d_lo.p; key.L = (void*)c->d_L.p;
     key.chain = (void*)c->d_chain_ev.p; key.K = c->K; key.tally_impl = c->tally_impl;
     key.S = (void*)c->d_S.p; key.round = (void*)c->d_round.p;
-    key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP; key.variant = c->band_fast;
+    key.BATCH = c->band_blocks + 4096 * c->skip; key.MCAP = c->MCAP + 7 * c->NEARCAP; key.variant = c->band_fast + 2 * c->tally_filter;
     if (memcmp(&key, &c->loop_key, sizeof key) != 0) {
         for (int g = 0; g < 4; ++g) {
             if (c->loop_exec[g]) { (void)hipGraphExecDestroy(c->loop_exec[g]); c->loop_exec[g] = nullptr; }
@@ -941,7 +955,7 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     const int np = c->npad, K = c->K;
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
                        (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, c->eval_src,
-                       (int)std::min<int64_t>(fin_from, 0x7fffffff));
+                       (int)std::min<int64_t>(fin_from, 0x7fffffff), 0, 0);
     c->eval_src = 0;
     c->ctr.kernel_launches++;
     std::vector<Span> tally_spans, resolve_spans;
@@ -954,9 +968,7 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     int shot = std::min<int64_t>(c->BATCH, 2 + (n_new_events / (12 * (int64_t)c->n) + 1) * 2);
     if (c->stat_iters > 0 && c->stat_events > 0) {
         const double pred = (double)c->stat_iters / (double)c->stat_events * (double)n_new_events;
-        static const double factor = getenv("SW_SHOT_FACTOR") ? atof(getenv("SW_SHOT_FACTOR")) : 1.0;
-        static const int extra = getenv("SW_SHOT_EXTRA") ? atoi(getenv("SW_SHOT_EXTRA")) : 2;
-        shot = std::max(2, (int)(pred * factor) + extra);
+        shot = std::max(2, (int)(pred * c->shot_pct / 100.0) + c->shot_extra);
     }
     shot = std::min(shot, 4096) & ~1;
     // `mid_loop` (the last sub-batch of a large call): the first shot stops `mid_pct` % of the way, the host looks at the loop
@@ -1021,6 +1033,111 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
         *tally_launches_out += cnt;
         for (size_t i = 0; i < resolve_spans.size() && (int)i < st.iter; ++i) { c->tm.resolve_ms += span_ms(resolve_spans[i]); c->tm.resolve_launches++; }
     }
+    c->ctr.band_events += (int64_t)st.band_events;
+    return SW_OK;
+}
+
+
+// ---- chained round loops (round 5): the loops of a call's sub-batches enqueued one behind the other --------------------------
+// The host used to sit between two loops: read the state back, find the next start round from the members' front rounds,
+// launch k_loop_init, enqueue the shot (5 gaps of 30-40 us per pass at 256 members / 1 M events).  Now loop i + 1 — k_loop_init
+// in its chained form, which finds the start round on the device and refuses if loop i did not end inside its shot — and its
+// first shot are enqueued while loop i runs; the host reads loop i's state (copied out before the chained start overwrote it)
+// one loop late, for the counters, the finalize launches of sub-batch i and the rare top-up.
+struct LoopRun {
+    int slot = 0;             // read-back slot (= sub-batch index)
+    int64_t limit = 0;        // events visible to the loop
+    int64_t n_new = 0;        // events of its sub-batch
+    int launched = 0;         // iterations enqueued for it
+    bool chained = false;
+};
+
+inline int predict_shot(const sw_ctx* c, int64_t n_new_events) {
+    int shot = std::min<int64_t>(c->BATCH, 2 + (n_new_events / (12 * (int64_t)c->n) + 1) * 2);
+    if (c->stat_iters > 0 && c->stat_events > 0) {
+        const double pred = (double)c->stat_iters / (double)c->stat_events * (double)n_new_events;
+        shot = std::max(2, (int)(pred * c->shot_pct / 100.0) + c->shot_extra);
+    }
+    return std::min(shot, 4096) & ~1;
+}
+
+// enqueue: start (host-computed start round, or chained), first shot, the copy of the read-back block into the run's slot
+template <int NW>
+int loop_begin(sw_ctx* c, LoopRun& run, int r_start, bool chained, int64_t prev_limit, const int32_t* visible_len, int64_t fin_from) {
+    const int np = c->npad;
+    const int shot = predict_shot(c, run.n_new);
+    if (!chained) CHK(ensure_rounds(c, c->R + shot + 8));   // (a loop started by the host finds the stream idle: the tables may move)
+    hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
+                       (int)run.limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, chained ? 0 : c->eval_src,
+                       (int)std::min<int64_t>(fin_from, 0x7fffffff), chained ? 1 : 0, (int)prev_limit);
+    if (!chained) c->eval_src = 0;
+    c->ctr.kernel_launches++;
+    CHK(launch_iterations<NW>(c, shot, nullptr, nullptr));
+    run.launched = shot;
+    run.chained = chained;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));
+    // (round 5, measured and dropped — profiles/r05h_knobs_256x1M.log: the copy of the LAST loop's state on a stream of its own,
+    // beside the tail of the call instead of in front of it: the pass went from 6.1 to 13 ms — a copy behind an event of another
+    // stream does not start when that event fires)
+    HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
+    return SW_OK;
+}
+
+// wait for the run's state; top up until the loop reports done; the book-keeping of a finished loop.  `next` = the run enqueued
+// (chained) behind this one, if any: when this loop did not end inside its shot, that start refused and its iterations went on
+// with this loop — *next_alive is cleared and the caller starts the next loop again, from the host.
+template <int NW>
+int loop_collect(sw_ctx* c, LoopRun& run, LoopRun* next, bool* next_alive) {
+    const int np = c->npad, K = c->K;
+    RState st{};
+    auto read_slot = [&](int slot) -> int {
+        HIPCHK(c, hipEventSynchronize(c->rb_events[slot]));
+        c->h_rb = c->h_rb_all + (size_t)slot * c->rb_bytes;
+        memcpy(&st, c->h_rb, sizeof st);
+        int ferr = 0;
+        memcpy(&ferr, c->h_rb + 2 * sizeof(RState), sizeof ferr);
+        memcpy(c->front_dev.data(), c->h_rb + 256, np * sizeof(int32_t));
+        if (ferr) return fail(c, SW_EIO, "can_see sweep gave up polling (code %d): internal protocol error", ferr);
+        if (st.err) return fail(c, SW_ERANGE, "round table capacity exceeded (internal)");
+        return SW_OK;
+    };
+    CHK(read_slot(run.slot));
+    if (st.N != (int)run.limit) return fail(c, SW_EIO, "chained round loop: state of another loop in slot %d (N=%d, expected %lld)", run.slot, st.N, (long long)run.limit);
+    if (!st.done && next && *next_alive) {
+        CHK(read_slot(next->slot));
+        if (st.N != (int)run.limit) return fail(c, SW_EIO, "chained round loop: the next loop started although this one had not ended");
+        run.launched += next->launched;
+        *next_alive = false;
+        HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));   // (this loop's last iteration so far lies behind the next run's shot)
+    }
+    while (!st.done) {
+        // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
+        if ((int64_t)run.launched > (int64_t)c->max_height + 2 + c->N / K + 4096)
+            return fail(c, SW_EIO, "round loop did not terminate after %d iterations (r=%d)", run.launched, st.r);
+        const int shot = run.launched < 8 ? 2 : (run.launched < 48 ? 8 : 4);
+        CHK(ensure_rounds(c, c->R + run.launched + shot + 4));   // (the stream is idle here: the tables may move)
+        CHK(launch_iterations<NW>(c, shot, nullptr, nullptr));
+        run.launched += shot;
+        HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
+        CHK(read_slot(run.slot));
+    }
+    if (run.n_new >= 4096) {  // keep the rate estimate to runs where it means something
+        c->stat_iters += st.iter;
+        c->stat_events += run.n_new;
+    }
+    c->eval_src = st.iter & 1;   // (what a host-started successor is told; a chained one reads it from the state)
+    c->R = st.max_round + 1;
+    if (c->unit_stake && c->tally_impl == 2) {
+        const int32_t* tc = reinterpret_cast<const int32_t*>(c->h_rb + ((unsigned char*)c->d_treecnt - c->d_rb));
+        for (int m = 0; m < np; ++m) c->ctr.tally_evals += tc[m];
+    } else
+        c->ctr.tally_evals += (int64_t)st.evals;
+    c->ctr.far_hops += (int64_t)st.far_hops;
+    c->ctr.round_iterations += st.iter;
     c->ctr.band_events += (int64_t)st.band_events;
     return SW_OK;
 }
@@ -1117,10 +1234,17 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             q = *end ? end + 1 : end;
         }
     } else if (K >= 65536 && c->pipe > 1) {
-        // a short first sub-batch (its sweep is the only one nothing overlaps), then even parts
+        // a short first sub-batch (its sweep is the only one nothing overlaps), then `pipe` parts.  Round 5: the parts are
+        // GRADUATED — weights 0.5, 0.9, 1.2, 1, 1, ... — because a loop now consumes events almost as fast as a sweep produces
+        // them (the loop of an even second part waited 0.17 ms for its sweep; profiles/r05l_knobs_256x1M.log: 6.09 -> 5.99 ms)
         const int64_t head = K / 16;
-        for (int s_ = 0; s_ < c->pipe; ++s_) {
-            const int64_t at = s_ == 0 ? head : head + (K - head) * s_ / c->pipe;
+        const int P = c->pipe;
+        double w[SW_PROV_ROWS], tot = 0.0;
+        for (int s_ = 0; s_ < P; ++s_) { w[s_] = P < 4 ? 1.0 : (s_ == 0 ? 0.5 : s_ == 1 ? 0.9 : s_ == 2 ? 1.2 : 1.0); tot += w[s_]; }
+        double acc = 0.0;
+        for (int s_ = 0; s_ < P; ++s_) {
+            const int64_t at = head + (int64_t)((double)(K - head) * (acc / tot));
+            acc += w[s_];
             const int64_t bnd = ((first + at) >> 12) << 12;
             if (bnd > cut.back() && bnd < first + K) cut.push_back(bnd);
         }
@@ -1294,29 +1418,152 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     std::vector<int32_t> clen_prev(bounds_h.begin(), bounds_h.begin() + np), clen(np, 0);
     bool aux_armed = false;
     std::function<int()> pending_aux = []() -> int { return SW_OK; };
-    for (int i = 0; i < S; ++i) {
-        const int64_t limit = cut[i + 1];
+    // start round of sub-batch i's loop = the smallest front round among the members it adds events to; a member's first event
+    // (swirld.py:195-198) opens round 0 for it: lo[0][m], chain position 0, uploaded in front of the loop
+    auto start_round = [&](int i, bool* row0_dirty) -> int {
         int r_start = 0x7fffffff;
-        bool row0_dirty = false;
+        *row0_dirty = false;
         std::copy(bounds_h.begin() + (size_t)(i + 1) * np, bounds_h.begin() + (size_t)(i + 2) * np, clen.begin());
         for (int m = 0; m < n; ++m) {
             if (clen[m] > clen_prev[m]) {  // member touched by this sub-batch
                 if (c->front[m] < 0) {     // its root (swirld.py:195-198): lo[0][m], chain position 0
                     c->lo0_h[m] = c->first_ev[m];
                     c->front[m] = 0;
-                    row0_dirty = true;
+                    *row0_dirty = true;
                 }
                 r_start = std::min(r_start, c->front[m]);
             }
         }
         if (r_start == 0x7fffffff) r_start = std::max(c->R - 1, 0);
+        return r_start;
+    };
+    auto upload_row0 = [&]() -> int {
+        HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        std::copy(c->front.begin(), c->front.end(), c->front_dev.begin());
+        HIPCHK(c, hipMemcpyAsync(c->d_front.p, c->front_dev.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        return SW_OK;
+    };
+    // what follows a finished loop i (its state is in c->h_rb): the chunk counters of its sweep, the host mirror of the front rounds,
+    // and the finalize / witness-row / voter-mask launches of its sub-batch, armed here and enqueued behind the next loop's shot
+    auto after_loop = [&](int i, int r_start, int64_t fin_from, hipEvent_t loop_done) -> int {
+        if (c->chunk_plan[i].G >= 2) {
+            // the sweep of this sub-batch is complete (the loop waited for it) and its counters came back with the
+            // loop state: provisional entries per chunk, entries the repair changed.  (A loop never reports SW_OK
+            // without at least one read-back behind a shot that waited for cs_events[i]: h_rb is this sub-batch's or a later one.)
+            const unsigned* pv = reinterpret_cast<const unsigned*>(c->h_rb + ((unsigned char*)c->d_prov - c->d_rb));
+            const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
+            for (int k = 1; k < pl.G; ++k) {
+                const unsigned cnt = pv[(size_t)i * SW_MAX_CHUNKS + k];
+                const int64_t len = pl.a[k + 1] - pl.a[k];
+                c->ctr.chunk_provisional += cnt;
+                if (cnt > (unsigned)std::min<int64_t>((len * c->n) / (32 * (c->chunk_cfg == 1 ? 2 : 4)), 0x7fffffff)) {
+                    c->ctr.chunk_resweeps++;
+                    c->chunks_off = true;   // this hashgraph has members silent for longer than the halo: sweep unchunked from now on
+                }
+            }
+            c->ctr.chunk_repaired += pv[(size_t)SW_PROV_ROWS * SW_MAX_CHUNKS + i];
+        }
+        // host mirror of the per-member front round (kept by the resolve kernel, read back with the loop state)
+        const int R = c->R;
+        for (int m = 0; m < n; ++m) c->front[m] = std::max(c->front[m], c->front_dev[m]);
+        clen_prev.swap(clen);
+        clk.mark(&c->stage_us[3]);
+        // The rounds of every event below `limit` are final now (later sub-batches only add lo
+        // entries that compare greater than every existing event), so their round numbers,
+        // sees-masks, witness rows and voter masks are produced on a third stream, overlapping the
+        // round loop of the next sub-batch — and ENQUEUED behind that loop's first shot (they must wait for
+        // this loop's kernels, which the aux stream learns from an event recorded behind them).
+        CHK(ensure_rounds(c, R + 2));
+        const int64_t a0 = fin_from, k0 = cut[i + 1] - fin_from;   // (the early part of the last sub-batch is done)
+        const int rs_ = r_start, i_ = i;
+        aux_armed = true;
+        const int S_ = S;
+        pending_aux = [c, np, R, a0, k0, rs_, i_, S_, loop_done, &fin_t0, &aux_armed]() -> int {
+            if (!aux_armed) return SW_OK;
+            aux_armed = false;
+            hipStream_t ax = c->stream_aux;
+            HIPCHK(c, hipStreamWaitEvent(ax, loop_done, 0));
+            if (i_ == 0 && c->profiling) { fin_t0 = next_event(c); (void)hipEventRecord(fin_t0, ax); }
+            // (a finalize that runs beside the next round loop is throttled: fewer workgroups, less pressure on the loop's gathers;
+            // the last one has nothing to hide behind and takes the whole GPU)
+            const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, i_ == S_ - 1 ? 8192 : c->fin_blocks);
+            CHK(launch_finalize<NW>(c, ax, a0, k0, R, blocks));
+            const int total = (R - rs_) * np;
+            if (total > 0)
+                hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, ax,
+                                   (const int*)c->d_lo.p, R, rs_, np, c->d_wit.p);
+            c->ctr.kernel_launches += 1;
+            return launch_voter_masks<NW>(c, rs_, R, ax);
+        };
+        clk.mark(&c->stage_us[4]);
+        return SW_OK;
+    };
+    // CHAINED loops (round 5; SW_CHAIN=0, profiling, the early finalize and the stage clocks take the loop-by-loop path below):
+    // loop i + 1 is enqueued while loop i runs (loop_begin / loop_collect).  Not chained: a sub-batch that holds a member's first
+    // event (its root row is uploaded by the host in front of the loop).
+    const bool can_chain = c->chain && !c->profiling && !c->debug_timing && c->mid_pct == 0 && S >= 2 && S <= SW_PROV_ROWS;
+    if (can_chain) {
+        std::vector<LoopRun> runs(S);
+        int cap_need = std::max(c->R, 1) + 64;
+        for (int i = 0; i < S; ++i) {
+            runs[i].slot = i;
+            runs[i].limit = cut[i + 1];
+            runs[i].n_new = cut[i + 1] - cut[i];
+            cap_need += predict_shot(c, runs[i].n_new) + 16;
+        }
+        // the round tables must not move while a chained loop is in flight: room for every predicted iteration up front
+        CHK(ensure_rounds(c, cap_need));
+        auto holds_a_root = [&](int i) -> bool {   // (decided from the cut table alone: a member with no event below cut[i] and one below cut[i + 1])
+            for (int m = 0; m < n; ++m)
+                if (bounds_h[(size_t)i * np + m] == 0 && bounds_h[(size_t)(i + 1) * np + m] > 0 && c->front[m] < 0) return true;
+            return false;
+        };
+        auto fits = [&](int i) -> bool {   // the tables hold the iterations enqueued so far plus this loop's shot
+            int need = std::max(c->R, 1) + 8;
+            for (int j = 0; j <= i; ++j) need += (j < i ? runs[j].launched : predict_shot(c, runs[j].n_new)) + 4;
+            return need <= c->Rcap;
+        };
+        std::vector<int> rs_host(S, 0);
+        {   // loop 0: from the host
+            bool dirty = false;
+            rs_host[0] = start_round(0, &dirty);
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[0], 0));
+            if (dirty) CHK(upload_row0());
+            clk.mark(&c->stage_us[1]);
+            CHK(loop_begin<NW>(c, runs[0], rs_host[0], false, 0, c->d_bounds.p + (size_t)np, c->fin_band ? cut[0] : 0x7fffffff));
+        }
+        for (int i = 0; i < S; ++i) {
+            r_min = std::min(r_min, rs_host[i]);
+            bool next_alive = false;
+            if (i + 1 < S && !holds_a_root(i + 1) && fits(i + 1)) {
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i + 1], 0));
+                CHK(loop_begin<NW>(c, runs[i + 1], 0, true, cut[i + 1], c->d_bounds.p + (size_t)(i + 2) * np, c->fin_band ? cut[i + 1] : 0x7fffffff));
+                next_alive = true;
+            }
+            CHK(pending_aux());   // the previous sub-batch's finalize launches, behind the shots just enqueued
+            CHK(loop_collect<NW>(c, runs[i], next_alive ? &runs[i + 1] : nullptr, &next_alive));
+            clk.mark(&c->stage_us[2]);
+            CHK(after_loop(i, rs_host[i], cut[i], c->shot_events[runs[i].slot]));
+            if (i + 1 < S) {
+                bool dirty = false;
+                rs_host[i + 1] = start_round(i + 1, &dirty);   // (what the chained start found on the device; the aux launches of i + 1 need it)
+                if (!next_alive) {
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i + 1], 0));
+                    if (dirty) CHK(upload_row0());
+                    CHK(loop_begin<NW>(c, runs[i + 1], rs_host[i + 1], false, 0, c->d_bounds.p + (size_t)(i + 2) * np, c->fin_band ? cut[i + 1] : 0x7fffffff));
+                } else if (dirty) {
+                    return fail(c, SW_EIO, "chained round loop started on a sub-batch that holds a member's first event (internal)");
+                }
+            }
+        }
+    } else
+    for (int i = 0; i < S; ++i) {
+        const int64_t limit = cut[i + 1];
+        bool row0_dirty = false;
+        const int r_start = start_round(i, &row0_dirty);
         r_min = std::min(r_min, r_start);
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i], 0));
-        if (row0_dirty) {
-            HIPCHK(c, hipMemcpyAsync(c->d_lo.p, c->lo0_h.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            std::copy(c->front.begin(), c->front.end(), c->front_dev.begin());
-            HIPCHK(c, hipMemcpyAsync(c->d_front.p, c->front_dev.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        }
+        if (row0_dirty) CHK(upload_row0());
         clk.mark(&c->stage_us[1]);
         const bool dbg_t = c->debug_timing && K >= 65536;
         const auto dbg_t0 = std::chrono::steady_clock::now();
@@ -1349,59 +1596,8 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                     i, (long long)(cut[i + 1] - cut[i]), w, l, (long long)its, its ? l * 1e3 / (double)its : 0.0);
         }
         clk.mark(&c->stage_us[2]);
-        if (c->chunk_plan[i].G >= 2) {
-            // the sweep of this sub-batch is complete (the loop waited for it) and its counters came back with the
-            // loop state: provisional entries per chunk, entries the repair changed.  (run_round_loop never returns SW_OK
-            // without at least one read-back behind a shot that waited for cs_events[i]: h_rb is this sub-batch's.)
-            const unsigned* pv = reinterpret_cast<const unsigned*>(c->h_rb + ((unsigned char*)c->d_prov - c->d_rb));
-            const sw_ctx::ChunkPlan& pl = c->chunk_plan[i];
-            for (int k = 1; k < pl.G; ++k) {
-                const unsigned cnt = pv[(size_t)i * SW_MAX_CHUNKS + k];
-                const int64_t len = pl.a[k + 1] - pl.a[k];
-                c->ctr.chunk_provisional += cnt;
-                if (cnt > (unsigned)std::min<int64_t>((len * c->n) / (32 * (c->chunk_cfg == 1 ? 2 : 4)), 0x7fffffff)) {
-                    c->ctr.chunk_resweeps++;
-                    c->chunks_off = true;   // this hashgraph has members silent for longer than the halo: sweep unchunked from now on
-                }
-            }
-            c->ctr.chunk_repaired += pv[(size_t)SW_PROV_ROWS * SW_MAX_CHUNKS + i];
-        }
-        // host mirror of the per-member front round (kept by the resolve kernel, read back with the loop state)
-        const int R = c->R;
-        for (int m = 0; m < n; ++m) c->front[m] = std::max(c->front[m], c->front_dev[m]);
-        clen_prev.swap(clen);
-        clk.mark(&c->stage_us[3]);
-        // The rounds of every event below `limit` are final now (later sub-batches only add lo
-        // entries that compare greater than every existing event), so their round numbers,
-        // sees-masks, witness rows and voter masks are produced on a third stream, overlapping the
-        // round loop of the next sub-batch — and ENQUEUED behind that loop's first shot (they must wait for
-        // this loop's kernels, which the aux stream learns from an event recorded here).
-        {
-            CHK(ensure_rounds(c, R + 2));
-            const int64_t a0 = fin_from, k0 = cut[i + 1] - fin_from;   // (the early part of the last sub-batch is done)
-            const int rs_ = r_start, i_ = i;
-            HIPCHK(c, hipEventRecord(c->ev_loop_done, c->stream));
-            aux_armed = true;
-            const int S_ = S;
-            pending_aux = [c, np, R, a0, k0, rs_, i_, S_, &fin_t0, &aux_armed]() -> int {
-                if (!aux_armed) return SW_OK;
-                aux_armed = false;
-                hipStream_t ax = c->stream_aux;
-                HIPCHK(c, hipStreamWaitEvent(ax, c->ev_loop_done, 0));
-                if (i_ == 0 && c->profiling) { fin_t0 = next_event(c); (void)hipEventRecord(fin_t0, ax); }
-                // (a finalize that runs beside the next round loop is throttled: fewer workgroups, less pressure on the loop's gathers;
-                // the last one has nothing to hide behind and takes the whole GPU)
-                const int blocks = (int)std::min<int64_t>((k0 + 3) / 4, i_ == S_ - 1 ? 8192 : c->fin_blocks);
-                CHK(launch_finalize<NW>(c, ax, a0, k0, R, blocks));
-                const int total = (R - rs_) * np;
-                if (total > 0)
-                    hipLaunchKernelGGL(k_witness_table, dim3((total + 255) / 256), dim3(256), 0, ax,
-                                       (const int*)c->d_lo.p, R, rs_, np, c->d_wit.p);
-                c->ctr.kernel_launches += 1;
-                return launch_voter_masks<NW>(c, rs_, R, ax);
-            };
-        }
-        clk.mark(&c->stage_us[4]);
+        HIPCHK(c, hipEventRecord(c->ev_loop_done, c->stream));
+        CHK(after_loop(i, r_start, fin_from, c->ev_loop_done));
     }
     CHK(pending_aux());   // the last sub-batch's
     span_end(c, sp_rl);
@@ -1463,7 +1659,10 @@ int fame_launch(sw_ctx* c, int max_c, int part, int nparts, Span* sp_el) {
     const uint32_t tot2 = 2u * c->tot;
     if (c->sw_dirty_from < R || R > c->Sw_rows) CHK(launch_voter_masks<NW>(c, std::min(c->sw_dirty_from, R), R, c->stream));
     c->sw_dirty_from = std::max(R, 1);
-    HIPCHK(c, hipMemsetAsync(c->d_newc.p + sizeof(FameCounters), 0, R, c->stream));
+    const bool tiled = NW >= 2 && c->elect_impl == 1;
+    if (tiled) CHK(dgrow(c, c->d_rsc, (size_t)3 * c->Rcap, 0));
+    hipLaunchKernelGGL(k_fame_prep, dim3(std::max(1, std::min(64, (3 * R + 255) / 256))), dim3(256), 0, c->stream, c->d_newc.p + sizeof(FameCounters), R,
+                       tiled ? c->d_rsc.p : nullptr, tiled ? 3 * R : 0);
     const int nblk = R - max_c - part > 0 ? (R - max_c - part + nparts - 1) / nparts : 0;
     const int call_idx = (int)c->fame_calls.size();
     if (sp_el) *sp_el = span_begin(c);
@@ -1473,8 +1672,6 @@ int fame_launch(sw_ctx* c, int max_c, int part, int nparts, Span* sp_el) {
                       tot2, c->coin_period, max_c, R, np, c->d_fam.p, c->d_cons.p, c->d_newc.p + sizeof(FameCounters), c->d_fc, c->d_dec_call.p, c->d_dec_by.p, call_idx, part, nparts
         if constexpr (NW >= 2) {  // NW threads per candidate, a round as 64 NW / CG workgroups of CG candidates (k_elections_tiled)
             if (c->elect_impl == 1) {
-                CHK(dgrow(c, c->d_rsc, (size_t)3 * c->Rcap, 0));
-                HIPCHK(c, hipMemsetAsync(c->d_rsc.p, 0, (size_t)3 * R * sizeof(int32_t), c->stream));
 #define SW_ELECT_TILED(CG_)                                                                                                             \
     do {                                                                                                                                \
         if (c->unit_stake) hipLaunchKernelGGL((k_elections_tiled<NW, true, CG_>), dim3(nblk * (64 * NW / (CG_))), dim3((CG_) * NW), 0, c->stream, SW_ELECT_ARGS, c->d_rsc.p);  \
@@ -2003,6 +2200,11 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     knob("SW_CHUNKS", 1, SW_MAX_CHUNKS, &c->chunks);
     knob("SW_CHUNK_CFG", 0, 2, &c->chunk_cfg);
     knob("SW_BAND_FAST", 0, 1, &c->band_fast);
+    if (c->npad > 256) c->tally_filter = 1;
+    knob("SW_TALLY_FILTER", 0, 1, &c->tally_filter);
+    knob("SW_CHAIN", 0, 1, &c->chain);
+    knob("SW_SHOT_PCT", 10, 400, &c->shot_pct);
+    knob("SW_SHOT_EXTRA", 0, 64, &c->shot_extra);
     knob("SW_CHUNK_MIN", 64, 1 << 30, &c->chunk_min);
     c->halo = 32 * (int64_t)c->npad;
     knob("SW_HALO", 0, 1 << 24, &c->halo);
@@ -2080,7 +2282,15 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
         c->rb_bytes = prov_off + (size_t)SW_PROV_ROWS * (SW_MAX_CHUNKS + 1) * sizeof(unsigned);
         CHIP(hipMalloc((void**)&c->d_rb, c->rb_bytes));
         CHIP(hipMemset(c->d_rb, 0, c->rb_bytes));
-        CHIP(hipHostMalloc((void**)&c->h_rb, c->rb_bytes, hipHostMallocDefault));
+        CHIP(hipHostMalloc((void**)&c->h_rb_all, c->rb_bytes * SW_PROV_ROWS, hipHostMallocDefault));
+        c->h_rb = c->h_rb_all;
+        for (int i = 0; i < SW_PROV_ROWS; ++i) {
+            hipEvent_t e1, e2;
+            CHIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            c->rb_events.push_back(e1);
+            CHIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            c->shot_events.push_back(e2);
+        }
         c->d_state = reinterpret_cast<RState*>(c->d_rb);
         c->d_flow_err = reinterpret_cast<int*>(c->d_rb + 2 * sizeof(RState));
         c->d_front.p = reinterpret_cast<int32_t*>(c->d_rb + 256);
@@ -2117,6 +2327,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     // proper starts at row 1
     CCHK(dgrow(c, c->d_Mb, ((size_t)c->MCAP + 1) * c->nw, 0));
     if (hipMemset(c->d_Mb.p, 0, (size_t)c->nw * sizeof(u64)) != hipSuccess) { sw_destroy(c); return SW_EIO; }
+    CCHK(dgrow(c, c->d_Pc, (size_t)c->MCAP + 1, 0));
+    if (hipMemset(c->d_Pc.p, 0, sizeof(int32_t)) != hipSuccess) { sw_destroy(c); return SW_EIO; }
     CCHK(fill_i32(c, c->d_evalround.p, 2 * np, -1));
     CCHK(fill_i32(c, c->d_evalpos.p, 2 * np, 0));
     CCHK(fill_i32(c, c->d_lo_r.p, 2 * np, SW_INF));
@@ -2164,9 +2376,11 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
     if (c->d_dbg) (void)hipFree(c->d_dbg);
     if (c->d_dbg_blk) (void)hipFree(c->d_dbg_blk);
-    dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_rsc); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb);
+    dfree(c->d_pos_next); dfree(c->d_found64); dfree(c->d_rsc); dfree(c->d_farslot); dfree(c->d_force); dfree(c->d_cand); dfree(c->d_gallop); dfree(c->d_small); dfree(c->d_Mb); dfree(c->d_Pc);
     if (c->d_rb) (void)hipFree(c->d_rb);
-    if (c->h_rb) (void)hipHostFree(c->h_rb);
+    if (c->h_rb_all) (void)hipHostFree(c->h_rb_all);
+    for (hipEvent_t e : c->rb_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->shot_events) (void)hipEventDestroy(e);
     if (c->h_fame) (void)hipHostFree(c->h_fame);
     if (c->d_err) (void)hipFree(c->d_err);
     dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
