@@ -1494,13 +1494,18 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // RIF events in flight at once.  Measured and dropped in round 4 (profiles/r04e_*, r04f_*): the rows as ONE vector load
     // per lane (dwordx4: 8.10 against 7.63 ms per pass), and a 16-bit side table of the rows relative to the event index
     // (half the bytes: 8.34 ms with ushort loads, 8.77 ms with vector loads) — four dword loads per row it stays.
-    const int g_first = mask_from >> 3;
-    for (int g = g_first + ((wave - g_first) % nwaves + nwaves) % nwaves; g * 8 < mhi; g += nwaves) {
-        // (up to 256 members masks are built for every band event: testing "can it be a hop at all" first costs a dependent load in
-        // a latency-bound phase, an unused mask 1 KB of row traffic.  Beyond — SKIP below — the phase is bound by the bytes of the rows.)
-        const int base = g * 8;
-        const int kk = base + (lane & 7);
-        const bool mine = lane < 8 && kk < mhi && kk >= mask_from;
+    // Groups of GE consecutive events: 8 up to 256 members; 4 beyond (round 5: a wave keeps the rows of 4 events in flight there, so a
+    // group of 8 was two passes — and with ~1.1 groups per wave the kernel lasted as long as the waves that drew TWO groups:
+    // profiles/r05o_loop_phases_1024.txt, the stamped workgroup's share done after 14 us, the kernel after 32)
+    constexpr int GE = NW <= 4 ? 8 : 4;
+    const int g_first = mask_from / GE;
+    for (int g = g_first + ((wave - g_first) % nwaves + nwaves) % nwaves; g * GE < mhi; g += nwaves) {
+        // (masks are built for every band event: testing "can it be a hop at all" first costs a dependent load, an unused mask the
+        // traffic of its row.  Round 5, measured at 1024 members — profiles/r05o_ab_1024x2M.log: rows below their creator's
+        // threshold skipped, 32.76 against 32.77 ms: uniform gossip has hardly any such event inside the band)
+        const int base = g * GE;
+        const int kk = base + (lane & (GE - 1));
+        const bool mine = lane < GE && kk < mhi && kk >= mask_from;
         u64 vm = __ballot(mine);
         // FINALIZE FROM THE BAND (round 4): a band event of this run's sub-batch that lies at or after its
         // creator's round-r witness has round >= r, and its mask against lo[r] — the ballots below — is its sees-mask if its round
@@ -1517,19 +1522,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
             const int fin_thr = s_thr[crk];   // lo[r][creator]: INF when the creator has no round-r witness
             return __ballot(mine && kk >= fin_thr && kk >= fin_from);
         };
-        constexpr int RIF = NW <= 4 ? 8 : 4;  // rows in flight per wave (one memory round trip per pass)
-        // SKIP (round 5, 512 members and more): a band event BELOW its creator's threshold lo[r][creator] has round < r — no candidate
-        // counts it as a hop (a hop is an entry >= lo[r][its column], the tally's `valid`), nothing reads its mask, and its round and
-        // sees-mask are not this pass's to write.  Its row (4 KB at 1024 members) is not fetched: one dependent look-up in a phase
-        // that moves 146 MB per iteration.
-        constexpr bool SKIP = NW >= 8;
-        u64 fin_pre = 0;
-        if constexpr (SKIP) {
-            asm volatile("" : "+v"(crk));
-            const int thr_c = s_thr[crk];
-            vm = __ballot(mine && kk >= thr_c);
-            fin_pre = __ballot(mine && kk >= thr_c && kk >= fin_from);
-        }
+        constexpr int RIF = GE;  // rows in flight per wave = a whole group (one memory round trip per group)
         if constexpr (FAST && RIF == 8) {
             // a FULL group — eight consecutive events, all of them band events (the common case): fixed indices, ONE 64-bit
             // row base per group and compile-time offsets (npad = 64 NW) instead of the ffs / mask bookkeeping and a
@@ -1579,7 +1572,7 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
                     v[u][j] = ks[u] >= 0 ? L[(size_t)ks[u] * npad + j * 64 + lane] : -1;
-                const u64 fin_m = SKIP ? fin_pre : fin_mask();   // (up to 256 members RIF covers a whole group: this loop makes one pass)
+                const u64 fin_m = fin_mask();   // (RIF covers a whole group: this loop makes one pass)
 #pragma unroll
             for (int u = 0; u < RIF; ++u)
                 if (ks[u] >= 0) {

@@ -35,9 +35,6 @@ def pytest_collection_finish(session):
         mk = it.get_closest_marker("heavy")
         if mk is not None:
             names.extend(a for a in mk.args if a not in names)
-    if names and _POOL is None and not session.config.option.collectonly:
-        from oracle_pool import OraclePool
-        _POOL = OraclePool(names)
     # torch ships its own copy of the HIP runtime under the system library's SONAME: imported BEFORE py-swirld_amd's library it
     # serves both (one runtime: torch streams can cross the C-ABI); imported after, it is a second runtime — and reports "No HIP
     # GPUs are available" once a windowed context has reserved its address range (profiles/r04r_pytest.log).  So: torch first,
@@ -51,6 +48,12 @@ def pytest_collection_finish(session):
                 torch.cuda.init()
         except Exception:   # (the tests themselves report what is missing)
             pass
+    # (the oracle pool AFTER the torch import: its threads call the library's host-side generator at once, which loads
+    # libswirld_hip.so — and with it the system HIP runtime — while this function is still running; with torch imported behind
+    # that, the process had two runtimes and the first sw_create of the session found no device: profiles/r05o_pytest.log)
+    if names and _POOL is None and not session.config.option.collectonly:
+        from oracle_pool import OraclePool
+        _POOL = OraclePool(names)
 
 
 def pytest_sessionfinish(session, exitstatus):
