@@ -386,7 +386,7 @@ def main():
     kernels = [
         fam(cs_name, tm["cansee_launches"], tm["cansee_kernel_ms"], 12 * n * (N - n), "hbm", cs_note),
         fam("k_resolve_band", tm["resolve_launches"], tm["resolve_ms"], cd["band_events"] * (4 * n + n // 8), "hbm/L2",
-            "4n B read + n/8 B written per band event; the replicated resolve step (latency) dominates its time"),
+            "4n B read + n/8 B written per band event; the replicated resolve step (latency: ~1 000 instructions and two dependent round trips) is most of its time"),
         fam(tally_name, tm["tally_launches"], tm["tally_ms"], cd["tally_evals"] * (4 * n + n * n // 8 + 8), "L2",
             "one can_see row + n gathered n-bit masks per evaluation (%d evaluations this pass%s); the gathers hit the "
             "L2-resident band table, so the rate is an L2-gather rate, not HBM"

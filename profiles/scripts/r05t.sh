@@ -1,0 +1,8 @@
+#!/bin/bash
+# GPU call r05t: k_tally_search with the exact tally by all four waves of the workgroup (beyond 256 members): parity at 1024 / 700 / 520 / 300
+# members, then speed
+O=gpurun_out/r05t; mkdir -p $O
+SW_TALLY_IMPL=3 timeout 900 python -m pytest tests/test_gpu_baseline_configs.py tests/test_gpu_partition.py -m gpu -x -q -k "1024 or coin or members or partition" > $O/pytest_wide_impl3.log 2>&1; tail -3 $O/pytest_wide_impl3.log
+timeout 500 python profiles/knob_sweep.py 1024 2000000 3 -- - SW_TALLY_IMPL=3 SW_TALLY_IMPL=3,SW_TALLY_K=16,SW_SKIP=8 SW_TALLY_IMPL=3,SW_TALLY_K=16,SW_SKIP=10 - > $O/knobs_1024x2M.log 2>&1; cat $O/knobs_1024x2M.log
+timeout 300 python profiles/knob_sweep.py 700 1000000 3 -- - SW_TALLY_IMPL=3 > $O/knobs_700x1M.log 2>&1; cat $O/knobs_700x1M.log
+GEN_MODE=2 GEN_P0=0.40 GEN_P1=0.02 timeout 300 python profiles/knob_sweep.py 1024 2000000 2 -- - SW_TALLY_IMPL=3 > $O/knobs_coin_1024x2M.log 2>&1; cat $O/knobs_coin_1024x2M.log

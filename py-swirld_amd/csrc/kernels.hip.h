@@ -2317,6 +2317,14 @@ k_tally_tree(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     SW_STAMP(stamp, it_, sb + 5);
 }
 
+// (Round 5, measured and dropped — profiles/r05s_*, r05t_*, r05u_*: a SEARCH form for 512 members and more, where an exact tally gathers
+// 128 KB: one workgroup of 4 waves per member CLASSIFIES every slot of the window by the popcount bounds of k_tally_bits' FILT, then
+// BISECTS the undecided run with exact tallies — 2.7 instead of 4.1 of them per member and round.  Parity-green at 300 ... 1024
+// members, and never faster: with the exact tally by one wave the bisection is three dependent 15-20 us evaluations (1024 members /
+// 2 M events 36.6 against 32.3 ms); with all four waves of the workgroup gathering a quarter of the hops each and meeting in LDS it
+// EQUALS the one-wave-per-slot kernel (32.36 against 32.41 ms; coin-round stress +1.8 %); with the rows of a wave's three slots in one
+// batch of loads, at 128 VGPRs, it spills and loses 5 %.  The 1024-member tally is not bound by the bytes of its exact
+// evaluations alone: every slot's row (4 KB) and a wave launch per slot cost as much.)
 // (Round 4, measured and dropped — profiles/r04j_*, r04k_*: the workgroups of k_tally_bits finish in dispatch order over 5.7 us
 // although a wave lives 2 us on average, which reads like a launch-rate bound.  A kernel with a quarter of the waves — one
 // workgroup per member, every wave evaluating four slots at once with interleaved gathers — does start and end within 1.9 us,

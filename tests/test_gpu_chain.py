@@ -66,7 +66,6 @@ def run_both(pkg, n, stream, calls):
 
 CASES = [
     # n, N, seed, mode, p0, p1, calls (fractions where a new call starts)
-    (64, 100000, 1, 0, 0.0, 0.0, []),
     (64, 140000, 2, 0, 0.0, 0.0, [0.5]),            # two large calls on one context (exhaustion marks carried over)
     (130, 90000, 3, 2, 0.3, 0.02, []),              # slow members: a loop that re-enters old rounds
     (20, 70000, 4, 1, 0.02, 0.0, []),               # two cliques
@@ -75,8 +74,8 @@ CASES = [
 
 
 @pytest.mark.parametrize("n,N,seed,mode,p0,p1,calls", CASES)
-@pytest.mark.parametrize("env", [{}, {"SW_SHOT_PCT": "50"}, {"SW_SHOT_PCT": "300"}, {"SW_PIPE": "8"}, {"SW_PIPE": "2", "SW_SHOT_PCT": "70"},
-                                 {"SW_CUTS": "0.01;0.03;0.1;0.3;0.6"}, {"SW_GRAPH": "0", "SW_SHOT_PCT": "50"}])
+@pytest.mark.parametrize("env", [{}, {"SW_SHOT_PCT": "50"}, {"SW_SHOT_PCT": "300", "SW_PIPE": "8"},
+                                 {"SW_CUTS": "0.01;0.03;0.1;0.3;0.6", "SW_SHOT_PCT": "70"}, {"SW_GRAPH": "0", "SW_SHOT_PCT": "50"}])
 def test_chained_loops_match_the_oracle_and_the_loop_by_loop_path(pkg, monkeypatch, n, N, seed, mode, p0, p1, calls, env):
     stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
     for k, v in env.items():
@@ -90,10 +89,11 @@ def test_chained_loops_match_the_oracle_and_the_loop_by_loop_path(pkg, monkeypat
     assert c1["rounds"] == c0["rounds"]
 
 
-@pytest.mark.parametrize("env", [{}, {"SW_SHOT_PCT": "50"}, {"SW_PIPE": "8"}])
+@pytest.mark.parametrize("env", [{}, {"SW_SHOT_PCT": "50", "SW_PIPE": "8"}])
 def test_a_sub_batch_that_holds_a_root_is_started_by_the_host(pkg, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SW_CHAIN", "1")
     for n, N, seed in [(40, 90000, 11), (100, 120000, 12)]:
         stream = late_joiners(n, N, seed)
         run_both(pkg, n, stream, [])
