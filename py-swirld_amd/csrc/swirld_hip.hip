@@ -182,6 +182,7 @@ struct sw_ctx {
     unsigned char* h_rb_all = nullptr;    // SW_PROV_ROWS pinned slots: the loops of a call's sub-batches are read back one behind the other
     std::vector<hipEvent_t> rb_events, shot_events;   // per slot: read-back complete / last iteration enqueued so far
     int shot_pct = 100, shot_extra = 2;   // SW_SHOT_PCT / SW_SHOT_EXTRA: a loop's first shot = predicted iterations x pct / 100 + extra (tests: 50 makes every loop top up)
+    int bridge = 16;                      // SW_BRIDGE: iterations of the short shot behind a chained start (the rest follows when the previous loop's state was read)
     int chain = 0;                        // SW_CHAIN: the loop of sub-batch i + 1 is enqueued behind the shot of loop i (k_loop_init, chained start).
                                           // Off by default (round 5, profiles/r05f_*, r05i_*): with an exact prediction of the iterations it
                                           // saves ~13 of the ~40 us between two loops (6.08 -> 6.06 ms per pass at 256 members / 1 M events);
@@ -1049,6 +1050,7 @@ struct LoopRun {
     int64_t limit = 0;        // events visible to the loop
     int64_t n_new = 0;        // events of its sub-batch
     int launched = 0;         // iterations enqueued for it
+    int rest = 0;             // a chained start enqueues a short BRIDGE shot only: the rest of the prediction follows once the previous loop's state was read
     bool chained = false;
 };
 
@@ -1065,7 +1067,13 @@ inline int predict_shot(const sw_ctx* c, int64_t n_new_events) {
 template <int NW>
 int loop_begin(sw_ctx* c, LoopRun& run, int r_start, bool chained, int64_t prev_limit, const int32_t* visible_len, int64_t fin_from) {
     const int np = c->npad;
-    const int shot = predict_shot(c, run.n_new);
+    int shot = predict_shot(c, run.n_new);
+    run.rest = 0;
+    // BRIDGE: a chained start that refuses (the previous loop did not end inside its shot) turns the iterations behind it into more
+    // iterations of the OLD loop — useful ones if they are few, a wasted shot if they are the new loop's whole prediction.  So the
+    // chained start is followed by a short shot only; the host reads the previous loop's state while the bridge runs (~0.25 ms of
+    // slack) and enqueues the rest behind it (loop_rest).
+    if (chained && shot > c->bridge + 8) { run.rest = shot - c->bridge; shot = c->bridge; }
     if (!chained) CHK(ensure_rounds(c, c->R + shot + 8));   // (a loop started by the host finds the stream idle: the tables may move)
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
                        (int)run.limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, chained ? 0 : c->eval_src,
@@ -1076,12 +1084,28 @@ int loop_begin(sw_ctx* c, LoopRun& run, int r_start, bool chained, int64_t prev_
     run.launched = shot;
     run.chained = chained;
     HIPCHK(c, hipGetLastError());
+    if (run.rest > 0) return SW_OK;   // (event + read-back follow the rest of the shot)
     HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));
     // (round 5, measured and dropped — profiles/r05h_knobs_256x1M.log: the copy of the LAST loop's state on a stream of its own,
     // beside the tail of the call instead of in front of it: the pass went from 6.1 to 13 ms — a copy behind an event of another
     // stream does not start when that event fires)
     HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
+    return SW_OK;
+}
+
+// the rest of a chained loop's first shot, behind its bridge (the previous loop was seen to have ended: the chained start took place)
+template <int NW>
+int loop_rest(sw_ctx* c, LoopRun& run) {
+    if (run.rest > 0) {
+        CHK(launch_iterations<NW>(c, run.rest, nullptr, nullptr));
+        run.launched += run.rest;
+        run.rest = 0;
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
+    }
     return SW_OK;
 }
 
@@ -1106,11 +1130,16 @@ int loop_collect(sw_ctx* c, LoopRun& run, LoopRun* next, bool* next_alive) {
     CHK(read_slot(run.slot));
     if (st.N != (int)run.limit) return fail(c, SW_EIO, "chained round loop: state of another loop in slot %d (N=%d, expected %lld)", run.slot, st.N, (long long)run.limit);
     if (!st.done && next && *next_alive) {
-        CHK(read_slot(next->slot));
-        if (st.N != (int)run.limit) return fail(c, SW_EIO, "chained round loop: the next loop started although this one had not ended");
+        // the chained start behind this loop refused: the iterations enqueued for the next loop (its bridge, or its whole shot) went
+        // on with this one.  Their outcome: a fresh copy of the state (the stream holds nothing else of the next loop yet).
         run.launched += next->launched;
+        next->rest = 0;
         *next_alive = false;
         HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));   // (this loop's last iteration so far lies behind the next run's shot)
+        HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
+        CHK(read_slot(run.slot));
+        if (st.N != (int)run.limit) return fail(c, SW_EIO, "chained round loop: the next loop started although this one had not ended");
     }
     while (!st.done) {
         // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
@@ -1520,7 +1549,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         };
         auto fits = [&](int i) -> bool {   // the tables hold the iterations enqueued so far plus this loop's shot
             int need = std::max(c->R, 1) + 8;
-            for (int j = 0; j <= i; ++j) need += (j < i ? runs[j].launched : predict_shot(c, runs[j].n_new)) + 4;
+            for (int j = 0; j <= i; ++j) need += (j < i ? runs[j].launched + runs[j].rest : predict_shot(c, runs[j].n_new)) + 4;
             return need <= c->Rcap;
         };
         std::vector<int> rs_host(S, 0);
@@ -1542,6 +1571,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             }
             CHK(pending_aux());   // the previous sub-batch's finalize launches, behind the shots just enqueued
             CHK(loop_collect<NW>(c, runs[i], next_alive ? &runs[i + 1] : nullptr, &next_alive));
+            if (next_alive) CHK(loop_rest<NW>(c, runs[i + 1]));   // (first thing after the state was read: the bridge is running)
             clk.mark(&c->stage_us[2]);
             CHK(after_loop(i, rs_host[i], cut[i], c->shot_events[runs[i].slot]));
             if (i + 1 < S) {
@@ -2203,6 +2233,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (c->npad > 256) c->tally_filter = 1;
     knob("SW_TALLY_FILTER", 0, 1, &c->tally_filter);
     knob("SW_CHAIN", 0, 1, &c->chain);
+    knob("SW_BRIDGE", 2, 512, &c->bridge);
+    c->bridge &= ~1;
     knob("SW_SHOT_PCT", 10, 400, &c->shot_pct);
     knob("SW_SHOT_EXTRA", 0, 64, &c->shot_extra);
     knob("SW_CHUNK_MIN", 64, 1 << 30, &c->chunk_min);

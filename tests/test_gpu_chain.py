@@ -3,7 +3,8 @@ sub-batch; with SW_CHAIN=1 (default) the loop of sub-batch i + 1 — k_loop_init
 on the device — is enqueued behind the first shot of loop i, and the host reads loop i's state one loop late.  Checked against
 the oracle, and against the loop-by-loop path (SW_CHAIN=0), with first shots that are too short (SW_SHOT_PCT=50: the chained
 start REFUSES, the iterations enqueued for the next loop go on with the old one, the host starts the next loop again), too
-long (no-op iterations), several cut schedules, members whose first event arrives late (a sub-batch that holds a root is
+long (no-op iterations), several cut schedules, bridge shots of 2 ... 512 iterations (SW_BRIDGE: a chained start is followed by a
+short shot, the rest of the prediction once the previous loop's state was read), members whose first event arrives late (a sub-batch that holds a root is
 never chained), and a second large call on the same context."""
 import numpy as np
 import pytest
@@ -75,7 +76,8 @@ CASES = [
 
 @pytest.mark.parametrize("n,N,seed,mode,p0,p1,calls", CASES)
 @pytest.mark.parametrize("env", [{}, {"SW_SHOT_PCT": "50"}, {"SW_SHOT_PCT": "300", "SW_PIPE": "8"},
-                                 {"SW_CUTS": "0.01;0.03;0.1;0.3;0.6", "SW_SHOT_PCT": "70"}, {"SW_GRAPH": "0", "SW_SHOT_PCT": "50"}])
+                                 {"SW_CUTS": "0.01;0.03;0.1;0.3;0.6", "SW_SHOT_PCT": "70"}, {"SW_GRAPH": "0", "SW_SHOT_PCT": "50"},
+                                 {"SW_BRIDGE": "2"}, {"SW_BRIDGE": "4", "SW_SHOT_PCT": "50"}, {"SW_BRIDGE": "512"}])
 def test_chained_loops_match_the_oracle_and_the_loop_by_loop_path(pkg, monkeypatch, n, N, seed, mode, p0, p1, calls, env):
     stream = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
     for k, v in env.items():
