@@ -1442,7 +1442,6 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
     hipEvent_t fin_t0 = nullptr;
     float tally_ms = 0.f;
     int tally_launches = 0;
-    int r_min = 0x7fffffff;
     // members' visible chain lengths before this call and after every sub-batch: rows of the cut table
     std::vector<int32_t> clen_prev(bounds_h.begin(), bounds_h.begin() + np), clen(np, 0);
     bool aux_armed = false;
@@ -1562,7 +1561,6 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             CHK(loop_begin<NW>(c, runs[0], rs_host[0], false, 0, c->d_bounds.p + (size_t)np, c->fin_band ? cut[0] : 0x7fffffff));
         }
         for (int i = 0; i < S; ++i) {
-            r_min = std::min(r_min, rs_host[i]);
             bool next_alive = false;
             if (i + 1 < S && !holds_a_root(i + 1) && fits(i + 1)) {
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i + 1], 0));
@@ -1591,7 +1589,6 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         const int64_t limit = cut[i + 1];
         bool row0_dirty = false;
         const int r_start = start_round(i, &row0_dirty);
-        r_min = std::min(r_min, r_start);
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i], 0));
         if (row0_dirty) CHK(upload_row0());
         clk.mark(&c->stage_us[1]);
