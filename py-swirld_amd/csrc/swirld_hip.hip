@@ -184,10 +184,11 @@ struct sw_ctx {
     int shot_pct = 100, shot_extra = 2;   // SW_SHOT_PCT / SW_SHOT_EXTRA: a loop's first shot = predicted iterations x pct / 100 + extra (tests: 50 makes every loop top up)
     int bridge = 16;                      // SW_BRIDGE: iterations of the short shot behind a chained start (the rest follows when the previous loop's state was read)
     int chain = 0;                        // SW_CHAIN: the loop of sub-batch i + 1 is enqueued behind the shot of loop i (k_loop_init, chained start).
-                                          // Off by default (round 5, profiles/r05f_*, r05i_*): with an exact prediction of the iterations it
-                                          // saves ~13 of the ~40 us between two loops (6.08 -> 6.06 ms per pass at 256 members / 1 M events);
-                                          // a shot that falls ONE iteration short makes the chained start refuse and the next loop's whole shot
-                                          // run as no-ops (SW_SHOT_EXTRA=1: 6.5 ms, 0: 7.1 ms) — the loop-by-loop path pays one host round trip
+                                          // Off by default (round 5, profiles/r05f_*, r05i_*, r05x_*): with an exact prediction of the iterations
+                                          // it saves ~13 of the ~40 us between two loops (6.05 -> 6.02 ms per pass at 256 members / 1 M events,
+                                          // -1.8 % at 64 members / 100 k events); with a prediction that falls short the chained start refuses,
+                                          // the bridge behind it goes on with the old loop and the host starts the new one again: 6.26-6.34 ms
+                                          // against 6.16-6.19 on the loop-by-loop path (one host round trip)
     size_t rb_bytes = 0;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;   // header of d_newc: the fame counters travel with the new_c flags in one copy
@@ -949,6 +950,18 @@ int launch_finalize(sw_ctx* c, hipStream_t ax, int64_t first, int64_t K, int R, 
     return SW_OK;
 }
 
+// first shot of a round loop: the predicted number of iterations for this many events (from the iterations-per-event rate of
+// earlier runs); without a measured rate about one round per 11.7 n events (SURVEY.md §8 probe) plus the round in progress —
+// a small call must not pay for a long first shot
+inline int predict_shot(const sw_ctx* c, int64_t n_new_events) {
+    int shot = std::min<int64_t>(c->BATCH, 2 + (n_new_events / (12 * (int64_t)c->n) + 1) * 2);
+    if (c->stat_iters > 0 && c->stat_events > 0) {
+        const double pred = (double)c->stat_iters / (double)c->stat_events * (double)n_new_events;
+        shot = std::max(2, (int)(pred * c->shot_pct / 100.0) + c->shot_extra);
+    }
+    return std::min(shot, 4096) & ~1;
+}
+
 template <int NW>
 int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, const int32_t* visible_len, float* tally_ms_out, int* tally_launches_out,
                    const std::function<int()>* after_first_shot = nullptr, const std::function<int(const RState&)>* mid_loop = nullptr,
@@ -962,16 +975,8 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     std::vector<Span> tally_spans, resolve_spans;
     RState st{};
     int launched = 0;
-    // first shot: the predicted number of iterations for this many events (from the
-    // iterations-per-event rate of earlier runs), then short top-ups until the loop reports done
-    // without a measured rate: about one round per 11.7 n events (SURVEY.md §8 probe) plus the
-    // round in progress — a small call must not pay for a long first shot
-    int shot = std::min<int64_t>(c->BATCH, 2 + (n_new_events / (12 * (int64_t)c->n) + 1) * 2);
-    if (c->stat_iters > 0 && c->stat_events > 0) {
-        const double pred = (double)c->stat_iters / (double)c->stat_events * (double)n_new_events;
-        shot = std::max(2, (int)(pred * c->shot_pct / 100.0) + c->shot_extra);
-    }
-    shot = std::min(shot, 4096) & ~1;
+    // first shot: the predicted number of iterations (predict_shot), then short top-ups until the loop reports done
+    int shot = predict_shot(c, n_new_events);
     // `mid_loop` (the last sub-batch of a large call): the first shot stops `mid_pct` % of the way, the host looks at the loop
     // state once — every event below the band of the round in progress has its final round by then — and hands it to the
     // caller, which finalizes those events beside the rest of the loop instead of behind it; the rest of the prediction follows
@@ -1053,15 +1058,6 @@ struct LoopRun {
     int rest = 0;             // a chained start enqueues a short BRIDGE shot only: the rest of the prediction follows once the previous loop's state was read
     bool chained = false;
 };
-
-inline int predict_shot(const sw_ctx* c, int64_t n_new_events) {
-    int shot = std::min<int64_t>(c->BATCH, 2 + (n_new_events / (12 * (int64_t)c->n) + 1) * 2);
-    if (c->stat_iters > 0 && c->stat_events > 0) {
-        const double pred = (double)c->stat_iters / (double)c->stat_events * (double)n_new_events;
-        shot = std::max(2, (int)(pred * c->shot_pct / 100.0) + c->shot_extra);
-    }
-    return std::min(shot, 4096) & ~1;
-}
 
 // enqueue: start (host-computed start round, or chained), first shot, the copy of the read-back block into the run's slot
 template <int NW>
