@@ -8,7 +8,12 @@ profiles/traffic.json, which bench.py quotes next to the algorithmic bytes.
   and bench.py reports the conservative (doubled) one.
   Launches that did no work (iterations replayed after the loop finished) are excluded: only
   dispatches above 5 % of the family's maximum count.
-Usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> <commit> <workload> <kernel-substring>..."""
+  The kernel trace that comes with the FETCH pass also gives every family's average launch duration as rocprofv3
+  sees it (`avg_us`): bench.py ranks the families by that duration x its own launch counts (its hipEvent brackets
+  around plain launches inflate the short loop kernels by 2-3 us each).
+  The file is keyed by WORKLOAD ("<members>x<events>x<generator mode>"): an existing file is extended, entries
+  measured on other kernel source (SHA-256 of kernels.hip.h + order.hip.h) are dropped.
+Usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> <commit> <workload-key> <command> <kernel-substring>..."""
 import glob
 import json
 import os
@@ -31,28 +36,62 @@ def per_kernel(d, counter, kernel):
             "sum_KiB": float(sel.sum())}
 
 
-def main(fd, wd, out, commit, workload, kernels):
+def kernel_source_sha256(root):
     import hashlib
+    h = hashlib.sha256()
+    for name in ("kernels.hip.h", "order.hip.h"):
+        with open(os.path.join(root, "py-swirld_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def avg_duration_us(d, kernel):
+    """average duration of the launches that did work (> 3 us: iterations replayed behind a finished loop return at once)"""
+    fs = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if not fs:
+        return None
+    df = pd.read_csv(fs[0])
+    kn = [c for c in df.columns if c.lower() == "kernel_name"][0]
+    a = [c for c in df.columns if c.lower() in ("start_timestamp", "start")][0]
+    b = [c for c in df.columns if c.lower() in ("end_timestamp", "end")][0]
+    sel = df[df[kn].str.contains(kernel, regex=False)]
+    if not len(sel):
+        return None
+    dur = (sel[b] - sel[a]) / 1e3
+    live = dur[dur > 3.0]
+    return round(float(live.mean()), 2) if len(live) else round(float(dur.mean()), 2)
+
+
+def main(fd, wd, out, commit, key, workload, kernels):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "py-swirld_amd", "csrc", "kernels.hip.h"), "rb") as fh:
-        ksha = hashlib.sha256(fh.read()).hexdigest()
-    res = {"commit": commit, "kernels_sha256": ksha, "workload": workload, "kernels": {}, "detail": {},
-           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; per kernel family the "
-                     "mean over the launches that did work; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 "
-                     "(FETCH_SIZE doubled per MI355X_MICROARCH.md HBM note)"}
+    ksha = kernel_source_sha256(root)
+    allw = {"kernels_sha256": ksha, "workloads": {},
+            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; per kernel family the "
+                      "mean over the launches that did work; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 "
+                      "(FETCH_SIZE doubled per MI355X_MICROARCH.md HBM note); avg_us = rocprofv3's own duration of the "
+                      "launches that did work, from the kernel trace of the FETCH pass"}
+    try:
+        old = json.load(open(out))
+        if old.get("kernels_sha256") == ksha:
+            allw["workloads"] = old.get("workloads", {})
+    except (OSError, ValueError):
+        pass
+    res = {"commit": commit, "workload": workload, "kernels": {}, "avg_us": {}, "detail": {}}
+    allw["workloads"][key] = res
     for k in kernels:
         f, w = per_kernel(fd, "FETCH_SIZE", k), per_kernel(wd, "WRITE_SIZE", k)
         if f is None or w is None:
             continue
         res["kernels"][k] = int((2 * f["mean_live_KiB"] + w["mean_live_KiB"]) * 1024)
+        res["avg_us"][k] = avg_duration_us(fd, k)
         res["detail"][k] = {"fetch_KiB_per_launch_raw": round(f["mean_live_KiB"], 1),
                             "write_KiB_per_launch_raw": round(w["mean_live_KiB"], 1),
                             "launches": f["dispatches"], "live_launches": f["live"],
                             "hbm_bytes_per_launch_uncorrected": int((f["mean_live_KiB"] + w["mean_live_KiB"]) * 1024),
                             "fetch_total_KiB_raw": round(f["sum_KiB"], 1), "write_total_KiB_raw": round(w["sum_KiB"], 1)}
-    json.dump(res, open(out, "w"), indent=1)
+    json.dump(allw, open(out, "w"), indent=1)
     print(json.dumps(res))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6:])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6], sys.argv[7:])

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profile recipe of the bench workload (run on the GPU box from the repo root):
-#   profiles/run_profiles.sh <tag> [bench args...]
+#   profiles/run_profiles.sh <tag> [bench args...]      (TRAFFIC_KEY=<members>x<events>x<mode> names the workload in traffic.json;
+#   default 256x1000000x0 = bench.py's default; TRAFFIC_JSON=<file> extends that file instead of starting one under gpurun_out)
 # writes gpurun_out/prof_<tag>/{kernel_stats.txt, pmc_summary.txt, traffic.json, loop_timeline.txt, *.log};
 # copy what should be judged into profiles/<tag>_*.  Counter passes run on their own (no tracing
 # domains besides the kernel trace), FETCH_SIZE and WRITE_SIZE in separate passes.
@@ -20,8 +21,10 @@ python profiles/loop_timeline.py "$DB" > $OUT/loop_timeline.txt 2>> $OUT/kt_run.
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python bench.py $PMCARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python bench.py $PMCARGS > $OUT/write.log 2>&1
-python profiles/collect_traffic.py $OUT/fetch $OUT/write $OUT/traffic.json "$COMMIT" "bench.py $PMCARGS" \
-    k_cansee_chunks k_cansee_fixup k_cansee_flow k_cansee_stream k_resolve_band k_tally_bits k_tally_tree k_elections k_voter_masks_bits k_finalize_events k_finalize_check k_finalize_listed > $OUT/traffic.log 2>&1
+TJ=${TRAFFIC_JSON:-$OUT/traffic.json}
+python profiles/collect_traffic.py $OUT/fetch $OUT/write $TJ "$COMMIT" "${TRAFFIC_KEY:-256x1000000x0}" "bench.py $PMCARGS" \
+    k_cansee_chunks k_cansee_fixup k_cansee_flow k_cansee_stream k_resolve_band k_tally_bits k_tally_tree k_elections k_voter_masks_bits k_finalize_events k_finalize_check k_finalize_listed \
+    k_order_walk k_order_median k_order_sort k_order_bounds > $OUT/traffic.log 2>&1
 # 3. wave / wait / cache counters
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS \
     --output-format csv -d $OUT/pmc1 -o p1 -- python bench.py $PMCARGS > $OUT/pmc1.log 2>&1

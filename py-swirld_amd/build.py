@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libswirld_hip.so")
 SOURCES = ["swirld_hip.hip", "synth.cpp"]
-DEPS = SOURCES + ["kernels.hip.h", "crypto.hip.h", "exact.hip.h", os.path.join("..", "..", "include", "swirld_hip.h")]
+DEPS = SOURCES + ["kernels.hip.h", "order.hip.h", "crypto.hip.h", "exact.hip.h", os.path.join("..", "..", "include", "swirld_hip.h")]
 
 
 def build(force=False, verbose=False):

@@ -2887,448 +2887,9 @@ k_elections_tiled(const int* __restrict__ wit, const u64* __restrict__ Sw, const
     }
 }
 
-// ---------------------------------------------------------------------------------
-// find_order (swirld.py:280-311), fork-free form.  Because "w sees x" (swirld.py:291-292:
-// can_see[w][c] is at least as high as x on creator c's chain) is inherited by every
-// ancestor of x, the set of already ordered events is ancestor-closed, i.e. a PREFIX of
-// every member's self-parent chain, and the events a decided round r newly orders on chain
-// c are the chain positions [ordered[c], q[r][c]) where q is the first position whose event
-// is no longer seen by famous witnesses holding more than half of the stake (:293).
-// ---------------------------------------------------------------------------------
-// q[ri][c] for round-list entry ri: one workgroup per entry, one thread per member c.
-// Whether position p is accepted depends on its event x only through "how much stake of the famous witnesses has
-// L[w][c] >= x": every famous witness accepts the positions up to its own latest-seen event of c, so the boundary lies
-// between the smallest and the largest of those entries — about a round of c's chain, 4 probes — and not anywhere in the
-// chain (12 probes at 1 M events: round 4, 0.89 -> see DESIGN.md N1).  `seq` = chain position of an event.
-__global__ void __launch_bounds__(1024)
-k_order_bounds(const int* __restrict__ fw_ev, const int* __restrict__ fw_off, const int* __restrict__ L,
-               const int* __restrict__ cr, const int* __restrict__ seq, const uint32_t* __restrict__ stake, uint32_t tot,
-               const int* __restrict__ chain_start, const int* __restrict__ chain_cnt,
-               const int* __restrict__ chain_ev, int npad, int* q) {
-    const int ri = blockIdx.x, c = threadIdx.x;
-    const int f0 = fw_off[ri], f1 = fw_off[ri + 1];
-    const int cs = chain_start[c], clen = chain_cnt[c];
-    int vmin = 0x7fffffff, vmax = -1;
-    uint32_t s_all = 0;
-    for (int i = f0; i < f1; ++i) {
-        const int w = fw_ev[i];
-        const int v = L[(size_t)w * npad + c];
-        vmin = v < vmin ? v : vmin;
-        vmax = v > vmax ? v : vmax;
-        s_all += stake[cr[w]];
-    }
-    // invariant: positions < a are accepted, positions >= b are not
-    int a = 0, b = 0;
-    if (f1 > f0 && 2u * s_all > tot && vmax >= 0 && clen > 0) {   // (else: not even the first event of c is accepted)
-        a = vmin >= 0 ? seq[vmin] + 1 : 0;   // seen by every famous witness
-        b = seq[vmax] + 1;                   // beyond the latest one any of them sees: by none
-        if (b > clen) b = clen;
-        if (a > b) a = b;
-    }
-    while (a < b) {
-        const int mid = (a + b) >> 1;
-        const int x = chain_ev[cs + mid];
-        uint32_t sum = 0;
-        for (int i = f0; i < f1; ++i) {
-            const int w = fw_ev[i];
-            if (L[(size_t)w * npad + c] >= x) sum += stake[cr[w]];
-        }
-        if (2u * sum > tot) a = mid + 1; else b = mid;
-    }
-    q[(size_t)ri * npad + c] = a;
-}
+// find_order (swirld.py:280-311): the kernels live in order.hip.h
+#include "order.hip.h"
 
-// consensus timestamp of every newly ordered event (swirld.py:295-305): one wave per event.
-// For each famous witness w that sees x, the sample is the timestamp of the first
-// self-ancestor of w that does NOT see x, or of w's creator's root (Q11) = the predecessor,
-// on the chain of w's creator m, of the first event of m that sees x (binary search: the
-// latest-seen entry for x's creator is monotone along a chain).
-template <int MAXS>
-__global__ void __launch_bounds__(256)
-k_order_times(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, int n_acc,
-              const int* __restrict__ fw_ev, const int* __restrict__ fw_off, const int* __restrict__ L,
-              const int* __restrict__ cr, const int* __restrict__ seq, const double* __restrict__ t,
-              const int* __restrict__ chain_start, const int* __restrict__ chain_ev, const int* __restrict__ ord_pos, int npad,
-              double* ts, int* err) {
-    __shared__ double s_t[4][MAXS];
-    const int lane = lane_id();
-    const int wib = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 4 + wib;
-    if (idx >= n_acc) return;
-    const int x = acc_ev[idx];
-    const int ri = acc_ri[idx];
-    const int c = cr[x];
-    const int f0 = fw_off[ri], f1 = fw_off[ri + 1];
-    double* st = s_t[wib];
-    int len = 0;
-    for (int base = f0; base < f1; base += 64) {
-        const int i = base + lane;
-        bool sees = false;
-        double sample = 0.0;
-        if (i < f1) {
-            const int w = fw_ev[i];
-            if (L[(size_t)w * npad + c] >= x) {
-                sees = true;
-                const int m = cr[w];
-                const int cs = chain_start[m];
-                // first position p in [ord_pos[m], seq[w]] with L[chain_m[p]][c] >= x: the ordered prefix of m's chain
-                // cannot see an unordered x (the ordered set is ancestor-closed), so the search never touches its
-                // rows — which is what lets old can_see rows be evicted (windowed table)
-                int lo_ = ord_pos[m], hi = seq[w];
-                if (lo_ > hi) lo_ = hi;
-                while (lo_ < hi) {
-                    const int mid = (lo_ + hi) >> 1;
-                    if (L[(size_t)chain_ev[cs + mid] * npad + c] >= x) hi = mid; else lo_ = mid + 1;
-                }
-                const int a = chain_ev[cs + (lo_ > 0 ? lo_ - 1 : 0)];
-                sample = t[a];
-            }
-        }
-        const u64 bal = __ballot(sees);
-        if (sees) st[len + __popcll(bal & ((1ull << lane) - 1ull))] = sample;
-        len += __popcll(bal);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // order statistics len/2 and (len+1)/2 of the sorted samples by rank counting (:304-305)
-    const int k1 = len / 2, k2 = (len + 1) / 2;
-    if (k2 >= len) {  // IndexError in the reference (len == 1, only with unequal stakes)
-        if (lane == 0) { atomicExch(err, 1); ts[idx] = 0.0; }
-        return;
-    }
-    double v1 = 0.0, v2 = 0.0;
-    bool h1 = false, h2 = false;
-    for (int i = lane; i < len; i += 64) {
-        const double ti = st[i];
-        int rank = 0;
-        for (int j = 0; j < len; ++j) {
-            const double tj = st[j];
-            rank += (tj < ti) || (tj == ti && j < i);
-        }
-        if (rank == k1) { v1 = ti; h1 = true; }
-        if (rank == k2) { v2 = ti; h2 = true; }
-    }
-    const u64 b1 = __ballot(h1), b2 = __ballot(h2);
-    const int l1 = __ffsll((long long)b1) - 1, l2 = __ffsll((long long)b2) - 1;
-    const double r1 = __shfl(v1, l1), r2 = __shfl(v2, l2);
-    if (lane == 0) ts[idx] = .5 * (r1 + r2);
-}
-
-
-// ---------------------------------------------------------------------------------
-// Bulk form of the same samples (a call that orders many events at once): instead of one binary
-// search of ~10 scattered 4-byte gathers per (event, famous witness) pair, ONE streaming pass builds
-// the transposed question "which is the first event of member m that sees x?" for every x that is
-// being ordered:
-//   FD[x][m] = min { y on m's chain : can_see[y][creator(x)] >= x }.
-// An event y newly sees, of member c's chain, exactly the positions (seq[L[sp(y)][c]], seq[L[y][c]]]
-// — what its row has beyond its self-parent's row — so thread (y, c) reads two table entries
-// (coalesced along c: whole 128-byte lines of the two rows) and writes FD[x][creator(y)] = y for the
-// few x in that range (one per (y, c) on average; every FD entry is written at most once).  The
-// consumer reads FD rows: "w sees x" is FD[x][creator(w)] <= w, and the sample (swirld.py:298-303, Q11)
-// is the timestamp of FD's self-parent (or of FD itself when it is a root).
-// Workgroup b handles the columns of group b % 8 (= its XCD, for locality only): the FD rows of one
-// chain are written from ONE XCD, whose L2 merges the 4-byte stores of a row's lines before they
-// leave (the rows being filled at any time are the recent ~13 n events: < 1 MB per XCD).
-// ---------------------------------------------------------------------------------
-template <int NW>
-__global__ void __launch_bounds__(256)
-k_order_firstdesc(const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-                  const int* __restrict__ seq, const int* __restrict__ chain_start, const int* __restrict__ chain_ev,
-                  const int* __restrict__ ordlo, const int* __restrict__ ordhi, int y0, int y1, int x0, int first_resident,
-                  int ytile, int* FD) {
-    constexpr int npad = 64 * NW;
-    constexpr int CG = 8;                 // columns per workgroup: 32 bytes of a row
-    constexpr int NG = npad / CG;         // column groups
-    constexpr int GPX = NG / 8;           // ... per XCD (= NW)
-    constexpr int YB = 256 / CG;          // events per pass of a workgroup
-    // Workgroup b runs on XCD b % 8 (observed; locality only).  The groups that share a 128-byte line of a row
-    // (4 groups = 32 columns) sit on ONE XCD, and consecutive workgroups of an XCD sweep its groups before they
-    // move to the next tile of events: the events in flight at any time span a few thousand indices, so the FD
-    // rows being filled (those of the last ~13 n events) stay in the XCD's L2 until their lines are complete.
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int sub = j % GPX, tile = j / GPX;
-    const int grp = GPX >= 4 ? (sub >> 2) * 32 + xcd * 4 + (sub & 3) : xcd * GPX + sub;
-    const int c = grp * CG + (int)(threadIdx.x % CG);
-    const int yl = (int)(threadIdx.x / CG);
-    const int plo = ordlo[c], phi = ordhi[c];   // chain positions of c ordered by this call: [plo, phi)
-    if (phi <= plo) return;
-    const int cs = chain_start[c];
-    const int ya = y0 + tile * ytile;
-    const int yb = ya + ytile < y1 ? ya + ytile : y1;
-    for (int y = ya + yl; y < yb; y += YB) {
-        const int v = L[(size_t)y * npad + c];
-        if (v < 0) continue;
-        const int s = sp[y];
-        int lower = 0;
-        if (s >= 0) {
-            if (s < first_resident) lower = plo;   // an evicted row is an ordered event's: it sees nothing unordered
-            else {
-                const int pv = L[(size_t)s * npad + c];
-                if (pv == v) continue;             // nothing new of c
-                lower = pv >= 0 ? seq[pv] + 1 : 0;
-            }
-        }
-        int upper = seq[v];
-        lower = lower > plo ? lower : plo;
-        upper = upper < phi - 1 ? upper : phi - 1;
-        if (upper < lower) continue;
-        const int m = cr[y];
-        // what the consumer wants of y: its self-parent a (the sample is t[a]; "w sees x" is a < w on one chain), or,
-        // for a root, y itself (every later event of its creator sees it): stored as -2 - y
-        const int val = s >= 0 ? s : -2 - y;
-        for (int p = lower; p <= upper; ++p) {
-            const int x = chain_ev[cs + p];
-            FD[(size_t)(x - x0) * npad + m] = val;
-        }
-    }
-}
-
-// Bitonic sort of 64 * E doubles held E per lane (element index = lane * E + r), ascending: the order statistics of a
-// wave's samples without the O(len^2) rank counting (21 cross-lane stages of E exchanges at E = 4 against ~560 LDS sweeps).
-template <int E>
-__device__ __forceinline__ void wave_bitonic_sort(double (&v)[E], const int lane) {
-    constexpr int NTOT = 64 * E;
-#pragma unroll
-    for (int k = 2; k <= NTOT; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= E) {
-                const int lj = j / E;                       // partner lane = lane ^ lj, same register
-                const bool lower = (lane & lj) == 0;        // this lane holds the smaller index of the pair
-#pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    const bool up = ((lane * E + r) & k) == 0;
-                    const double o = __shfl_xor(v[r], lj);
-                    const double mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
-                    v[r] = (lower == up) ? mn : mx;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    if ((r & j) == 0) {
-                        const bool up = ((lane * E + r) & k) == 0;
-                        const double a = v[r], b2 = v[r | j];
-                        const bool sw = (a > b2) == up;
-                        v[r] = sw ? b2 : a;
-                        v[r | j] = sw ? a : b2;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int MAXS>
-__global__ void __launch_bounds__(256)
-k_order_times_fd(const int* __restrict__ acc_ev, const int* __restrict__ acc_ri, int n_acc,
-                 const int* __restrict__ fw_ev, const int* __restrict__ fw_cr, const int* __restrict__ fw_off,
-                 const int* __restrict__ FD, int x0, const double* __restrict__ t, int npad,
-                 double* ts, int* err) {
-    constexpr int E = MAXS / 64;
-    __shared__ double s_t[4][MAXS];
-    const int lane = lane_id();
-    const int wib = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 4 + wib;
-    if (idx >= n_acc) return;
-    const int x = acc_ev[idx];
-    const int ri = acc_ri[idx];
-    const int f0 = fw_off[ri], f1 = fw_off[ri + 1];
-    const int* row = FD + (size_t)(x - x0) * npad;
-    double* st = s_t[wib];
-    int len = 0;
-    for (int base = f0; base < f1; base += 64) {
-        const int i = base + lane;
-        bool sees = false;
-        double sample = 0.0;
-        if (i < f1) {
-            const int w = fw_ev[i];
-            const int v = row[fw_cr[i]];   // -1: no event of w's creator sees x; -2 - y: its root y does; else the self-parent of the first one that does
-            // the first event of w's creator that sees x is w or a self-ancestor of w  <=>  w sees x (swirld.py:291-292)
-            if (v <= -2 || (v >= 0 && v < w)) {
-                sees = true;
-                sample = t[v >= 0 ? v : -2 - v];   // the first self-ancestor that does NOT see x; a root stands for itself (Q11)
-            }
-        }
-        const u64 bal = __ballot(sees);
-        if (sees) st[len + __popcll(bal & ((1ull << lane) - 1ull))] = sample;
-        len += __popcll(bal);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // order statistics len/2 and (len+1)/2 of the sorted samples (:304-305)
-    const int k1 = len / 2, k2 = (len + 1) / 2;
-    if (k2 >= len) {  // IndexError in the reference (len == 1, only with unequal stakes)
-        if (lane == 0) { atomicExch(err, 1); ts[idx] = 0.0; }
-        return;
-    }
-    double v[E];
-    const double inf = __longlong_as_double(0x7ff0000000000000ll);
-#pragma unroll
-    for (int r = 0; r < E; ++r) v[r] = lane * E + r < len ? st[lane * E + r] : inf;
-    wave_bitonic_sort<E>(v, lane);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < E; ++r) st[lane * E + r] = v[r];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) ts[idx] = .5 * (st[k1] + st[k2]);
-}
-
-// The events a call newly orders, round by round (swirld.py:288-293 as chain segments): segment (round entry i,
-// member m) = chain positions [start, q[i][m]) of m, written at offset `off` of the round-major list.  The host
-// computes start / off from the q table (one pass over entries x members); the events themselves never visit it.
-__global__ void k_order_segments(const int* __restrict__ q, const int* __restrict__ seg_start, const int* __restrict__ seg_off,
-                                 const int* __restrict__ chain_start, const int* __restrict__ chain_ev, int npad, int total,
-                                 int* acc_ev, int* acc_ri) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int st = seg_start[i];
-    if (st < 0) return;
-    const int m = i % npad, ri = i / npad;
-    const int len = q[i] - st, off = seg_off[i];
-    const int* src = chain_ev + chain_start[m] + st;
-    for (int k = 0; k < len; ++k) { acc_ev[off + k] = src[k]; acc_ri[off + k] = ri; }
-}
-
-// whitening key of a decided round (swirld.py:285): XOR of its famous witnesses' signatures
-__global__ void k_order_white(const int* __restrict__ fw_ev, const int* __restrict__ fw_off,
-                              const unsigned char* __restrict__ sig, unsigned char* white) {
-    const int ri = blockIdx.x, b = threadIdx.x;  // 64 threads = 64 signature bytes
-    unsigned char w = 0;
-    for (int i = fw_off[ri]; i < fw_off[ri + 1]; ++i) w ^= sig[(size_t)fw_ev[i] * 64 + b];
-    white[(size_t)ri * 64 + b] = w;
-}
-
-// final order inside a round (swirld.py:306): sort by (consensus timestamp, whitened signature).
-// One workgroup per round, bitonic sort in LDS on (ts, first 8 key bytes as a big-endian
-// integer); a round with more than SORT_CAP events, or with two events equal in both (the
-// remaining 56 key bytes would have to decide), is flagged and sorted by the host instead.
-constexpr int SORT_CAP = 4096;
-__global__ void __launch_bounds__(1024)
-k_order_sort(const int* __restrict__ acc_ev, const long long* __restrict__ acc_off,
-             const double* __restrict__ ts, const unsigned char* __restrict__ sig,
-             const unsigned char* __restrict__ white, int* out_ev, int* host_flag) {
-    __shared__ double s_ts[SORT_CAP];
-    __shared__ u64 s_k8[SORT_CAP];
-    __shared__ int s_ev[SORT_CAP];
-    const int ri = blockIdx.x, tid = threadIdx.x;
-    const long long a0 = acc_off[ri];
-    const int cnt = (int)(acc_off[ri + 1] - a0);
-    if (cnt > SORT_CAP) {
-        if (tid == 0) host_flag[ri] = 1;
-        return;
-    }
-    int m = 1;
-    while (m < cnt) m <<= 1;
-    u64 wk = 0;
-    for (int b = 0; b < 8; ++b) wk = (wk << 8) | white[(size_t)ri * 64 + b];
-    for (int i = tid; i < m; i += 1024) {
-        if (i < cnt) {
-            const int e = acc_ev[a0 + i];
-            u64 k = 0;
-            for (int b = 0; b < 8; ++b) k = (k << 8) | sig[(size_t)e * 64 + b];
-            s_ts[i] = ts[a0 + i];
-            s_k8[i] = k ^ wk;
-            s_ev[i] = e;
-        } else {
-            s_ts[i] = __longlong_as_double(0x7ff0000000000000ll);  // +inf padding sorts last
-            s_k8[i] = ~0ull;
-            s_ev[i] = 0x7fffffff;
-        }
-    }
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < m; i += 1024) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const double ta = s_ts[i], tb = s_ts[l];
-                    const u64 ka = s_k8[i], kb = s_k8[l];
-                    const int ea = s_ev[i], eb = s_ev[l];
-                    const bool gt = ta > tb || (ta == tb && (ka > kb || (ka == kb && ea > eb)));
-                    if (gt == up) {
-                        s_ts[i] = tb; s_ts[l] = ta;
-                        s_k8[i] = kb; s_k8[l] = ka;
-                        s_ev[i] = eb; s_ev[l] = ea;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    int tie = 0;
-    for (int i = tid; i < cnt; i += 1024) {
-        out_ev[a0 + i] = s_ev[i];
-        if (i + 1 < cnt && s_ts[i] == s_ts[i + 1] && s_k8[i] == s_k8[i + 1]) tie = 1;
-    }
-    if (__syncthreads_or(tie) && tid == 0) host_flag[ri] = 1;
-}
-
-// ... and the rounds with more than SORT_CAP events (non-uniform hashgraphs: a round of two cliques or of a hashgraph with
-// slow members orders 4-6 k events at 256 members; the host sorted those: 88-107 ms per 1 M events, profiles/r04_final3_*):
-// the same bitonic network over a scratch copy of the keys in global memory (20 B per event, L2-resident), one workgroup per
-// such round, thread p of a stage owns the pair (i, i | j).  big_ri[b] = round-list entry, big_off[b] .. big_off[b + 1] =
-// its slice of the scratch arrays (length = the next power of two).  Ties stay with the host (flag), as above.
-__global__ void __launch_bounds__(1024)
-k_order_sort_big(const int* __restrict__ big_ri, const long long* __restrict__ big_off,
-                 const int* __restrict__ acc_ev, const long long* __restrict__ acc_off,
-                 const double* __restrict__ ts, const unsigned char* __restrict__ sig,
-                 const unsigned char* __restrict__ white, double* k_ts, u64* k_k8, int* k_ev, int* out_ev, int* host_flag) {
-    const int ri = big_ri[blockIdx.x], tid = threadIdx.x;
-    const long long s0 = big_off[blockIdx.x];
-    const int m = (int)(big_off[blockIdx.x + 1] - s0);
-    const long long a0 = acc_off[ri];
-    const int cnt = (int)(acc_off[ri + 1] - a0);
-    double* T = k_ts + s0;
-    u64* K8 = k_k8 + s0;
-    int* E = k_ev + s0;
-    u64 wk = 0;
-    for (int b = 0; b < 8; ++b) wk = (wk << 8) | white[(size_t)ri * 64 + b];
-    for (int i = tid; i < m; i += 1024) {
-        if (i < cnt) {
-            const int e = acc_ev[a0 + i];
-            u64 k = 0;
-            for (int b = 0; b < 8; ++b) k = (k << 8) | sig[(size_t)e * 64 + b];
-            T[i] = ts[a0 + i];
-            K8[i] = k ^ wk;
-            E[i] = e;
-        } else {
-            T[i] = __longlong_as_double(0x7ff0000000000000ll);  // +inf padding sorts last
-            K8[i] = ~0ull;
-            E[i] = 0x7fffffff;
-        }
-    }
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < (m >> 1); p += 1024) {
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const int l = i | j;
-                const bool up = (i & k) == 0;
-                const double ta = T[i], tb = T[l];
-                const u64 ka = K8[i], kb = K8[l];
-                const int ea = E[i], eb = E[l];
-                const bool gt = ta > tb || (ta == tb && (ka > kb || (ka == kb && ea > eb)));
-                if (gt == up) {
-                    T[i] = tb; T[l] = ta;
-                    K8[i] = kb; K8[l] = ka;
-                    E[i] = eb; E[l] = ea;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    int tie = 0;
-    for (int i = tid; i < cnt; i += 1024) {
-        out_ev[a0 + i] = E[i];
-        if (i + 1 < cnt && T[i] == T[i + 1] && K8[i] == K8[i + 1]) tie = 1;
-    }
-    const int any = __syncthreads_or(tie);
-    if (tid == 0) host_flag[ri] = any;   // (k_order_sort, launched before, flagged the round as oversize)
-}
 
 // ---------------------------------------------------------------------------------
 // Gossip side: what a peer needs from this node, from the device-resident state.

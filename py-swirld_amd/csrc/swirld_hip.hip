@@ -34,6 +34,30 @@ struct DBuf {
     size_t cap = 0;  // elements
 };
 
+// growable int32 array in pinned host memory: the ordered events (Node.transactions) — device copies land in it directly
+struct PinnedVec {
+    int32_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    size_t size() const { return n; }
+    int32_t* data() { return p; }
+    int32_t& operator[](size_t i) { return p[i]; }
+    void clear() { n = 0; }
+    bool resize(size_t m) {   // (only while nothing is in flight into the array)
+        if (m > cap) {
+            const size_t nc = std::max(m, cap + cap / 2 + 4096);
+            int32_t* q = nullptr;
+            if (hipHostMalloc((void**)&q, nc * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (n) memcpy(q, p, n * sizeof(int32_t));
+            if (p) (void)hipHostFree(p);
+            p = q;
+            cap = nc;
+        }
+        n = m;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+};
+
 }  // namespace
 
 // can_see table under HIP virtual memory management (windowed mode, sw_set_window): ONE reserved address
@@ -249,20 +273,32 @@ struct sw_ctx {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     // find_order state (swirld.py:53-57): ordered events are a prefix of every member's chain
-    std::vector<int32_t> transactions;
+    PinnedVec transactions;
     std::vector<int32_t> ord_pos;            // per member: chain positions already ordered
     std::vector<unsigned char> sig_h;        // host copy of the signatures (whitening, sort key)
     std::vector<int32_t> chain_start_h, chain_ev_h;
-    DBuf<int32_t> d_fw_ev, d_fw_off, d_q, d_acc_ev, d_acc_ri, d_sorted, d_hostflag;
+    DBuf<int32_t> d_q, d_acc_ev, d_acc_ri, d_sorted, d_hostflag;
+    // find_order, tables of a call (order.hip.h): the rounds asked for, f_w per entry as a member-indexed row, ordered prefixes per entry,
+    // [start | length | offset] of the newly ordered chain segments per (entry, member), events per entry, the block that is read back
+    // ([OrderInfo][new ordered prefixes: npad][acc_off: entries + 1]), per-group tables of the bulk kernels
+    DBuf<int32_t> d_ord_rounds, d_fwm, d_ordat, d_rowsum, d_grp;
+    DBuf<long long> d_oblk;
+    char* h_ord = nullptr;           // pinned staging of a find_order call (rounds and ordered prefixes up, the block and the host-sort flags down)
+    size_t h_ord_cap = 0;
+    hipStream_t stream_ord = nullptr;     // bulk find_order: the samples of group g run here beside the walk of group g + 1 ...
+    hipStream_t stream_srt[2] = {nullptr, nullptr};   // ... and its sort (one workgroup per round: ~0.2 ms whatever the number of rounds) and read-back here, groups alternating
+    std::vector<hipEvent_t> ord_events;   // per group: table walked / table consumed; then the ends of the three side streams
+    int32_t* h_ord_stage = nullptr;  // pinned: the [i0, i1) round-entry bounds of the groups of a bulk call
+    size_t h_ord_stage_cap = 0;
     DBuf<int32_t> d_big_ri, d_sk_ev;     // find_order: rounds too large for the LDS sort and their scratch keys (k_order_sort_big)
     DBuf<long long> d_big_off;
     DBuf<double> d_sk_ts;
     DBuf<u64> d_sk_k8;
-    DBuf<int32_t> d_seg;   // find_order: [start | offset] of the newly ordered chain segments per (round entry, member)
-    DBuf<int32_t> d_fw_cr, d_fd, d_ordhi;   // bulk find_order: creators of the famous witnesses, first-descendant table, end of the ordered chain segments
-    DBuf<long long> d_acc_off;
+    DBuf<int32_t> d_seg;
+    DBuf<int32_t> d_fd;    // bulk find_order: first-descendant table of one group of round entries, [member][chain][position] (k_order_walk)
     DBuf<unsigned char> d_white;
     DBuf<double> d_ts;
+    DBuf<double> d_tch;    // bulk find_order: timestamps in chain-pool order (k_order_tchain)
     int* d_err = nullptr;
     int* d_flow_err = nullptr;   // set by k_cansee_flow when a polling loop gives up (protocol bug)
     u64* d_flow_dbg = nullptr;   // SW_DEBUG_TIMING: counters of the dataflow sweep (column 0)
@@ -1837,6 +1873,28 @@ int window_evict(sw_ctx* c) {
     return SW_OK;
 }
 
+// pinned staging of a find_order call: [rounds: nr][ordpos: npad][OrderInfo init][read-back block = the layout of d_oblk][hostflag: nr]
+int ensure_order_host(sw_ctx* c, size_t bytes) {
+    if (bytes <= c->h_ord_cap) return SW_OK;
+    if (c->h_ord) { HIPCHK(c, hipDeviceSynchronize()); (void)hipHostFree(c->h_ord); c->h_ord = nullptr; c->h_ord_cap = 0; }
+    size_t nc = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc((void**)&c->h_ord, nc, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(c, SW_ENOMEM, "hipHostMalloc(%zu bytes) for find_order failed", nc); }
+    c->h_ord_cap = nc;
+    return SW_OK;
+}
+
+// pinned staging of the group bounds of a bulk find_order call
+int ensure_order_stage(sw_ctx* c, size_t ints) {
+    if (ints <= c->h_ord_stage_cap) return SW_OK;
+    if (c->h_ord_stage) { HIPCHK(c, hipDeviceSynchronize()); (void)hipHostFree(c->h_ord_stage); c->h_ord_stage = nullptr; c->h_ord_stage_cap = 0; }
+    const size_t nc = ints * 2 + 256;
+    if (hipHostMalloc((void**)&c->h_ord_stage, nc * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(c, SW_ENOMEM, "hipHostMalloc for find_order's group table failed"); }
+    c->h_ord_stage_cap = nc;
+    return SW_OK;
+}
+
+constexpr int order_tile(int NW) { return NW <= 8 ? 16 : 8; }   // positions per tile of k_order_median: 16 KB of LDS at 256 members (8 workgroups per CU)
+
 template <int NW>
 int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, int64_t cap, int64_t* n_out) {
     const int np = c->npad, n = c->n;
@@ -1853,246 +1911,287 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
     rounds.erase(std::unique(rounds.begin(), rounds.end()), rounds.end());
     const int nr = (int)rounds.size();
     if (nr == 0) return SW_OK;
-    CHK(ensure_pool_h(c));
     if (c->payload_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_payload, 0));  // timestamps / signatures of a bulk append
     if (rounds.front() < 0 || rounds.back() >= c->R)
         return fail(c, SW_ERANGE, "find_order: round outside [0, %d) (KeyError in the reference)", c->R);
-    const int rmin = rounds.front(), rmax = rounds.back();
-    std::vector<int32_t> wit((size_t)(rmax - rmin + 1) * np);
-    std::vector<signed char> fam((size_t)(rmax - rmin + 1) * np);
-    HIPCHK(c, hipMemcpyAsync(wit.data(), c->d_wit.p + (size_t)rmin * np, wit.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(fam.data(), c->d_fam.p + (size_t)rmin * np, fam.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<int32_t> fw_ev, fw_off(nr + 1, 0);
-    for (int i = 0; i < nr; ++i) {
-        const size_t row = (size_t)(rounds[i] - rmin) * np;
-        for (int m = 0; m < n; ++m) {
-            const int32_t w = wit[row + m];
-            if (w < 0) continue;
-            if (fam[row + m] < 0)
-                return fail(c, SW_EINVAL, "find_order: round %d has an undecided witness (KeyError on self.famous[w], swirld.py:284)", rounds[i]);
-            if (fam[row + m]) fw_ev.push_back(w);  // f_w, swirld.py:284
-        }
-        fw_off[i + 1] = (int32_t)fw_ev.size();
-    }
-    CHK(dgrow(c, c->d_fw_ev, std::max<size_t>(fw_ev.size(), 1), 0));
-    CHK(dgrow(c, c->d_fw_off, nr + 1, 0));
+    if ((int64_t)(nr + 1) * np >= (1ll << 31)) return fail(c, SW_ERANGE, "find_order: %d rounds x %d columns exceed 2^31 table entries", nr, np);
+    // ---- tables of the call, all on the device: f_w (:284), q (:288-293), ordered prefixes per entry, segment offsets ----
+    // device block read back with ONE copy: [OrderInfo][ord_new: npad ints][acc_off: nr + 1 long long]
+    const size_t oblk_ll = sizeof(OrderInfo) / 8 + (size_t)np / 2 + (size_t)nr + 1;
+    const size_t h_rounds_off = 0, h_ordpos_off = ((size_t)nr * 4 + 63) & ~(size_t)63, h_init_off = h_ordpos_off + (size_t)np * 4,
+                 h_blk_off = h_init_off + 64, h_flag_off = h_blk_off + ((oblk_ll * 8 + 63) & ~(size_t)63);
+    CHK(ensure_order_host(c, h_flag_off + (size_t)nr * 4));
+    int32_t* h_rounds = reinterpret_cast<int32_t*>(c->h_ord + h_rounds_off);
+    int32_t* h_ordpos = reinterpret_cast<int32_t*>(c->h_ord + h_ordpos_off);
+    OrderInfo* h_init = reinterpret_cast<OrderInfo*>(c->h_ord + h_init_off);
+    const OrderInfo* h_info = reinterpret_cast<const OrderInfo*>(c->h_ord + h_blk_off);
+    const int32_t* h_ordnew = reinterpret_cast<const int32_t*>(c->h_ord + h_blk_off + sizeof(OrderInfo));
+    const long long* acc_off = reinterpret_cast<const long long*>(c->h_ord + h_blk_off + sizeof(OrderInfo) + (size_t)np * 4);
+    int32_t* hostflag = reinterpret_cast<int32_t*>(c->h_ord + h_flag_off);
+    std::copy(rounds.begin(), rounds.end(), h_rounds);
+    std::fill(h_ordpos, h_ordpos + np, 0);
+    std::copy(c->ord_pos.begin(), c->ord_pos.end(), h_ordpos);
+    *h_init = OrderInfo{0, 0x7fffffff, 0, {0, 0, 0, 0}};
+    CHK(dgrow(c, c->d_ord_rounds, nr, 0));
+    CHK(dgrow(c, c->d_fwm, (size_t)2 * nr * np, 0));   // [famous witness | its chain position] per (entry, member)
     CHK(dgrow(c, c->d_q, (size_t)nr * np, 0));
-    if (!fw_ev.empty())
-        HIPCHK(c, hipMemcpyAsync(c->d_fw_ev.p, fw_ev.data(), fw_ev.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_fw_off.p, fw_off.data(), (nr + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_order_bounds, dim3(nr), dim3(np), 0, c->stream, (const int*)c->d_fw_ev.p, (const int*)c->d_fw_off.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_seq.p, (const uint32_t*)c->d_stake.p, c->tot,
-                       (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, np, c->d_q.p);
-    c->ctr.kernel_launches++;
-    std::vector<int32_t> q((size_t)nr * np);
-    HIPCHK(c, hipMemcpyAsync(q.data(), c->d_q.p, q.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    CHK(dgrow(c, c->d_ordat, (size_t)(nr + 1) * np, 0));
+    CHK(dgrow(c, c->d_seg, (size_t)3 * nr * np, 0));
+    CHK(dgrow(c, c->d_rowsum, nr, 0));
+    CHK(dgrow(c, c->d_oblk, oblk_ll, 0));
+    CHK(dgrow(c, c->d_ordpos, np, 0));
+    OrderInfo* d_info = reinterpret_cast<OrderInfo*>(c->d_oblk.p);
+    int32_t* d_ordnew = reinterpret_cast<int32_t*>(c->d_oblk.p) + sizeof(OrderInfo) / 4;
+    long long* d_acc_off = c->d_oblk.p + sizeof(OrderInfo) / 8 + np / 2;
+    int32_t *d_seg_start = c->d_seg.p, *d_seg_len = c->d_seg.p + (size_t)nr * np, *d_seg_off = c->d_seg.p + (size_t)2 * nr * np;
+    HIPCHK(c, hipMemcpyAsync(c->d_ord_rounds.p, h_rounds, (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ordpos.p, h_ordpos, (size_t)np * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_info, h_init, sizeof(OrderInfo), hipMemcpyHostToDevice, c->stream));
+    int32_t* d_fwseq = c->d_fwm.p + (size_t)nr * np;
+    hipLaunchKernelGGL(k_order_prep, dim3(nr), dim3(np), 0, c->stream, (const int*)c->d_ord_rounds.p, (const int*)c->d_wit.p,
+                       (const signed char*)c->d_fam.p, (const int*)c->d_seq.p, n, np, c->d_fwm.p, d_fwseq, d_info);
+    hipLaunchKernelGGL(k_order_bounds<NW>, dim3(nr, NW), dim3(64 * NW), 0, c->stream, (const int*)c->d_fwm.p, (const int*)c->d_L.p,
+                       (const int*)c->d_seq.p, (const uint32_t*)c->d_stake.p, c->tot, (const int*)c->d_chain_start.p,
+                       (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, n, (int)(c->N - 1), c->d_q.p);
+    hipLaunchKernelGGL(k_order_runmax, dim3(1), dim3(np), 0, c->stream, (const int*)c->d_q.p, (const int*)c->d_ordpos.p, nr, np,
+                       c->d_ordat.p, d_seg_start, d_seg_len, d_ordnew);
+    hipLaunchKernelGGL(k_order_rowscan, dim3(nr), dim3(np), 0, c->stream, (const int*)d_seg_len, np, d_seg_off, c->d_rowsum.p);
+    hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(1024), 0, c->stream, (const int*)c->d_rowsum.p, nr, d_acc_off, d_info);
+    c->ctr.kernel_launches += 5;
+    HIPCHK(c, hipMemcpyAsync(c->h_ord + h_blk_off, c->d_oblk.p, oblk_ll * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    lap("bounds");
-    // newly ordered chain segments per round (tbd = everything at or after ord_pos): the host walks the q table
-    // (entries x members), the events are gathered on the device (k_order_segments)
-    std::vector<int32_t> ord = c->ord_pos;
-    std::vector<int64_t> acc_off(nr + 1, 0);
-    std::vector<int32_t> seg((size_t)2 * nr * np, -1);   // [start | offset] per (entry, member); start -1: empty
-    int64_t n_acc = 0;
-    std::vector<int32_t> ord_at((size_t)(nr + 1) * n);   // chain positions ordered before round entry i
-    for (int i = 0; i < nr; ++i) {
-        std::copy(ord.begin(), ord.end(), ord_at.begin() + (size_t)i * n);
-        for (int m = 0; m < n; ++m) {
-            const int hi = q[(size_t)i * np + m];
-            if (hi > ord[m]) {
-                seg[(size_t)i * np + m] = ord[m];
-                seg[(size_t)nr * np + (size_t)i * np + m] = (int32_t)n_acc;
-                n_acc += hi - ord[m];
-                ord[m] = hi;
-            }
-        }
-        acc_off[i + 1] = n_acc;
-    }
-    std::copy(ord.begin(), ord.end(), ord_at.begin() + (size_t)nr * n);
+    HIPCHK(c, hipGetLastError());
+    lap("tables");
+    if (h_info->undecided_ri != 0x7fffffff)
+        return fail(c, SW_EINVAL, "find_order: round %d has an undecided witness (KeyError on self.famous[w], swirld.py:284)", rounds[h_info->undecided_ri]);
+    const int64_t n_acc = h_info->n_acc;
     if (n_acc > 0x7ffffff0ll) return fail(c, SW_ERANGE, "find_order: more than 2^31 events in one call");
     std::vector<int32_t> acc_ev;   // host copy: fetched only for the rounds the host has to sort
-    lap("segments");
-    std::vector<double> ts;                                   // (host copy of the timestamps: only for rounds the host sorts)
-    std::vector<int32_t> hostflag(nr, 0);
+    std::vector<double> ts;        // (host copy of the timestamps: only for rounds the host sorts)
+    std::vector<unsigned char> white_h;
+    std::fill(hostflag, hostflag + nr, 0);
     const size_t tx_at = c->transactions.size();
-    c->transactions.resize(tx_at + (size_t)n_acc);              // the device-sorted order lands in place
+    if (!c->transactions.resize(tx_at + (size_t)n_acc)) return fail(c, SW_ENOMEM, "pinned host memory for the ordered events");   // the device-sorted order lands in place
     int32_t* sorted = c->transactions.data() + tx_at;
+    bool copied_early_ok = false, any_host_sorted = false;   // out_events already holds the order / the host re-sorted rounds of it
     if (n_acc) {
         CHK(dgrow(c, c->d_acc_ev, n_acc, 0));
         CHK(dgrow(c, c->d_acc_ri, n_acc, 0));
         CHK(dgrow(c, c->d_ts, n_acc, 0));
-        CHK(dgrow(c, c->d_seg, seg.size(), 0));
-        HIPCHK(c, hipMemcpyAsync(c->d_seg.p, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_order_segments, dim3((unsigned)(((size_t)nr * np + 255) / 256)), dim3(256), 0, c->stream, (const int*)c->d_q.p,
-                           (const int*)c->d_seg.p, (const int*)c->d_seg.p + (size_t)nr * np, (const int*)c->d_chain_start.p,
-                           (const int*)c->d_chain_ev.p, np, nr * np, c->d_acc_ev.p, c->d_acc_ri.p);
-        c->ctr.kernel_launches++;
-        HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
-        CHK(dgrow(c, c->d_ordpos, np, 0));
-        {
-            std::vector<int32_t> op_(np, 0);
-            std::copy(c->ord_pos.begin(), c->ord_pos.end(), op_.begin());
-            HIPCHK(c, hipMemcpyAsync(c->d_ordpos.p, op_.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
-        // A call that orders many events: the first-descendant table (k_order_firstdesc) instead of one binary
-        // search per (event, famous witness) pair.  Same samples, by construction and by test (SW_ORDER_BULK=<events>
-        // moves the threshold, 0 = never).
-        const int64_t bulk_min = getenv("SW_ORDER_BULK") ? atoll(getenv("SW_ORDER_BULK")) : 16384;   // (read per call: the tests force either path)
-        const bool bulk = bulk_min > 0 && n_acc >= bulk_min;
-        if (bulk) {
-            // The table is built for GROUPS of consecutive round entries whose events span at most SW_ORDER_SLAB_MB [128] of
-            // FD rows: a slab that stays allocated (and mostly cache-resident) instead of one table as large as the
-            // can_see rows of everything the call orders.
-            const int64_t slab_rows = std::max<int64_t>(4096, ((getenv("SW_ORDER_SLAB_MB") ? atoll(getenv("SW_ORDER_SLAB_MB")) : 128) << 20) / ((int64_t)np * 4));
-            std::vector<int32_t> fw_cr(fw_ev.size());
-            for (size_t i = 0; i < fw_ev.size(); ++i) fw_cr[i] = c->cr[fw_ev[i]];
-            CHK(dgrow(c, c->d_fw_cr, std::max<size_t>(fw_cr.size(), 1), 0));
-            HIPCHK(c, hipMemcpyAsync(c->d_fw_cr.p, fw_cr.data(), fw_cr.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            struct Group { int i0, i1; int64_t x0, x1, y1; };
-            std::vector<Group> groups;
-            auto span_of = [&](int i0, int i1, int64_t* x0, int64_t* x1) {   // events ordered by the entries [i0, i1)
-                *x0 = c->N; *x1 = 0;
-                const int32_t *lo_ = ord_at.data() + (size_t)i0 * n, *hi_ = ord_at.data() + (size_t)i1 * n;
-                for (int m = 0; m < n; ++m)
-                    if (hi_[m] > lo_[m]) {
-                        const int32_t* ch = c->chain_ev_h.data() + (size_t)c->chain_start_h[m];
-                        *x0 = std::min<int64_t>(*x0, ch[lo_[m]]);
-                        *x1 = std::max<int64_t>(*x1, (int64_t)ch[hi_[m] - 1] + 1);
-                    }
-            };
-            for (int i0 = 0; i0 < nr;) {
-                int i1 = i0 + 1;
-                int64_t x0, x1;
-                span_of(i0, i1, &x0, &x1);
-                while (i1 < nr) {   // grow the group while its span fits the slab
-                    int64_t nx0, nx1;
-                    span_of(i0, i1 + 1, &nx0, &nx1);
-                    if (nx1 - nx0 > slab_rows) break;
-                    x0 = nx0; x1 = nx1; ++i1;
-                }
-                int64_t y1 = 0;
-                for (int j = fw_off[i0]; j < fw_off[i1]; ++j) y1 = std::max<int64_t>(y1, (int64_t)fw_ev[j] + 1);
-                if (acc_off[i1] > acc_off[i0]) groups.push_back({i0, i1, x0, x1, y1});
-                i0 = i1;
-            }
-            int64_t max_rows = 0;
-            for (const Group& g : groups) max_rows = std::max(max_rows, g.x1 - g.x0);
-            CHK(dgrow(c, c->d_fd, (size_t)max_rows * np, 0));
-            CHK(dgrow(c, c->d_ordhi, (size_t)2 * np * std::max<size_t>(groups.size(), 1), 0));
-            std::vector<int32_t> oh((size_t)2 * np * std::max<size_t>(groups.size(), 1), 0);
-            for (size_t gi = 0; gi < groups.size(); ++gi) {
-                std::copy(ord_at.begin() + (size_t)groups[gi].i0 * n, ord_at.begin() + (size_t)(groups[gi].i0 + 1) * n, oh.begin() + (size_t)2 * np * gi);
-                std::copy(ord_at.begin() + (size_t)groups[gi].i1 * n, ord_at.begin() + (size_t)(groups[gi].i1 + 1) * n, oh.begin() + (size_t)2 * np * gi + np);
-            }
-            HIPCHK(c, hipMemcpyAsync(c->d_ordhi.p, oh.data(), oh.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            lap("uploads");
-            for (size_t gi = 0; gi < groups.size(); ++gi) {
-                const Group& g = groups[gi];
-                HIPCHK(c, hipMemsetAsync(c->d_fd.p, 0xff, (size_t)(g.x1 - g.x0) * np * sizeof(int32_t), c->stream));
-                const int ytile = 64;    // (two passes of 32 events per workgroup: the events in flight stay within a few thousand indices)
-                const int64_t tiles = (g.y1 - g.x0 + ytile - 1) / ytile;
-                if (tiles > 0)
-                    hipLaunchKernelGGL(k_order_firstdesc<NW>, dim3((unsigned)(tiles * 8 * NW)), dim3(256), 0, c->stream, (const int*)c->d_L.p,
-                                       (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
-                                       (const int*)c->d_chain_ev.p, (const int*)c->d_ordhi.p + (size_t)2 * np * gi, (const int*)c->d_ordhi.p + (size_t)2 * np * gi + np,
-                                       (int)g.x0, (int)g.y1, (int)g.x0, (int)c->first_resident, ytile, c->d_fd.p);
-                const int64_t a0 = acc_off[g.i0], na = acc_off[g.i1] - acc_off[g.i0];
-                hipLaunchKernelGGL(k_order_times_fd<64 * NW>, dim3((unsigned)((na + 3) / 4)), dim3(256), 0, c->stream,
-                                   (const int*)c->d_acc_ev.p + a0, (const int*)c->d_acc_ri.p + a0, (int)na, (const int*)c->d_fw_ev.p,
-                                   (const int*)c->d_fw_cr.p, (const int*)c->d_fw_off.p, (const int*)c->d_fd.p, (int)g.x0,
-                                   (const double*)c->d_t.p, np, c->d_ts.p + a0, c->d_err);
-                c->ctr.kernel_launches += 2;
-            }
-            HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging vectors above are locals)
-            lap("firstdesc+times");
-        } else {
-        hipLaunchKernelGGL(k_order_times<64 * NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
-                           (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fw_ev.p,
-                           (const int*)c->d_fw_off.p, (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_seq.p,
-                           (const double*)c->d_t.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
-                           (const int*)c->d_ordpos.p, np, c->d_ts.p, c->d_err);
-        c->ctr.kernel_launches++;
-        }
-        // device sort of every round's segment by (ts, first 8 whitened key bytes)
         CHK(dgrow(c, c->d_white, (size_t)nr * 64, 0));
-        CHK(dgrow(c, c->d_acc_off, nr + 1, 0));
         CHK(dgrow(c, c->d_sorted, n_acc, 0));
         CHK(dgrow(c, c->d_hostflag, nr, 0));
-        std::vector<long long> acc_off_ll(acc_off.begin(), acc_off.end());
-        HIPCHK(c, hipMemcpyAsync(c->d_acc_off.p, acc_off_ll.data(), (nr + 1) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_hostflag.p, 0, nr * sizeof(int32_t), c->stream));
-        hipLaunchKernelGGL(k_order_white, dim3(nr), dim3(64), 0, c->stream, (const int*)c->d_fw_ev.p, (const int*)c->d_fw_off.p,
-                           (const unsigned char*)c->d_sig.p, c->d_white.p);
-        hipLaunchKernelGGL(k_order_sort, dim3(nr), dim3(1024), 0, c->stream, (const int*)c->d_acc_ev.p,
-                           (const long long*)c->d_acc_off.p, (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p,
-                           (const unsigned char*)c->d_white.p, c->d_sorted.p, c->d_hostflag.p);
-        c->ctr.kernel_launches += 2;
-        {   // rounds too large for the LDS sort: the same network over global scratch, one workgroup per such round
-            std::vector<int32_t> big_ri;
-            std::vector<long long> big_off{0};
-            for (int i = 0; i < nr; ++i) {
-                const int64_t len = acc_off[i + 1] - acc_off[i];
-                if (len <= SORT_CAP || getenv("SW_ORDER_BIG_HOST")) continue;   // (test hook: oversize rounds to the host, as before round 4)
-                int64_t m = 1;
-                while (m < len) m <<= 1;
-                big_ri.push_back(i);
-                big_off.push_back(big_off.back() + m);
+        // rounds too large for the LDS sort: the same network over global scratch, one workgroup per such round (behind everything else)
+        std::vector<int32_t> big_ri;
+        std::vector<long long> big_off{0};
+        for (int i = 0; i < nr; ++i) {
+            const int64_t len = acc_off[i + 1] - acc_off[i];
+            if (len <= SORT_CAP || getenv("SW_ORDER_BIG_HOST")) continue;   // (test hook: oversize rounds to the host, as before round 4)
+            int64_t m = 1;
+            while (m < len) m <<= 1;
+            big_ri.push_back(i);
+            big_off.push_back(big_off.back() + m);
+        }
+        // device sort of the round entries [i0, i1) by (ts, first 8 whitened key bytes), then their part of the order to the host
+        auto sort_and_fetch = [&](hipStream_t st, int i0, int i1, bool fetch) -> int {
+            hipLaunchKernelGGL(k_order_sort, dim3(i1 - i0), dim3(1024), 0, st, (const int*)c->d_acc_ev.p,
+                               (const long long*)d_acc_off, (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p,
+                               (const unsigned char*)c->d_white.p, i0, c->d_sorted.p, c->d_hostflag.p);
+            c->ctr.kernel_launches++;
+            const int64_t a0 = acc_off[i0], na = acc_off[i1] - a0;
+            if (fetch && na) HIPCHK(c, hipMemcpyAsync(sorted + a0, c->d_sorted.p + a0, na * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            return SW_OK;
+        };
+        const bool fetch_early = big_ri.empty();   // (oversize rounds are sorted last: then the whole order travels at the end)
+        // what only the consumers of the table need (the ordered events round-major, the whitening keys, cleared flags): enqueued
+        // on THEIR stream, beside the first walk
+        auto consumer_preamble = [&](hipStream_t st) -> int {
+            HIPCHK(c, hipMemsetAsync(c->d_hostflag.p, 0, nr * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_order_segments, dim3((unsigned)(((size_t)nr * np + 255) / 256)), dim3(256), 0, st, (const int*)d_seg_start,
+                               (const int*)d_seg_len, (const int*)d_seg_off, (const long long*)d_acc_off, (const int*)c->d_chain_start.p,
+                               (const int*)c->d_chain_ev.p, np, nr * np, c->d_acc_ev.p, c->d_acc_ri.p);
+            hipLaunchKernelGGL(k_order_white, dim3(nr), dim3(1024), 0, st, (const int*)c->d_fwm.p, n, np,
+                               (const unsigned char*)c->d_sig.p, c->d_white.p);
+            c->ctr.kernel_launches += 2;
+            return SW_OK;
+        };
+        // A call that orders many events: the first-descendant table (k_order_walk) instead of one binary search per
+        // (event, famous witness) pair.  Same samples, by construction and by test (SW_ORDER_BULK=<events> moves the
+        // threshold, 0 = never).
+        const int64_t bulk_min = getenv("SW_ORDER_BULK") ? atoll(getenv("SW_ORDER_BULK")) : 16384;   // (read per call: the tests force either path)
+        // Beyond 512 members every call takes the table: the search kernel's 16-word instance keeps ~90 wave masks alive around
+        // its divergent chain searches, the compiler spills them, and the timestamps came back wrong AND different from run
+        // to run (1024 members x 100 k events, profiles/r06_order_search_16_words.txt) — it is not built.
+        const bool bulk = NW > 8 || (bulk_min > 0 && n_acc >= bulk_min);
+        hipStream_t tail = c->stream;   // the stream the last kernels of the call are on
+        if (bulk) {
+            // The table is built for GROUPS of consecutive round entries whose events fit SW_ORDER_SLAB_MB [128 per 256 columns]
+            // of table — a slab that stays allocated instead of one table as large as the can_see rows of everything the call
+            // orders — and there are TWO slabs: the samples, the sort and the read-back of group g run on a second stream
+            // beside the walk of group g + 1 (the walk is bound by its stores, the samples by their selection loops).
+            constexpr int P = order_tile(NW);
+            const int64_t slab_mb = getenv("SW_ORDER_SLAB_MB") ? atoll(getenv("SW_ORDER_SLAB_MB")) : 128 * std::max(1, NW / 4);
+            const int64_t pad = (int64_t)P * np;   // every chain rounds its positions up to whole tiles
+            const int64_t slab_pos = std::max<int64_t>(2 * pad, (slab_mb << 20) / ((int64_t)n * 4));
+            struct Group { int i0, i1; };
+            std::vector<Group> groups;
+            int64_t stride = 0;
+            for (int i0 = 0; i0 < nr;) {
+                int i1 = i0 + 1;
+                while (i1 < nr && acc_off[i1 + 1] - acc_off[i0] + pad <= slab_pos) ++i1;
+                if (acc_off[i1] > acc_off[i0]) { groups.push_back({i0, i1}); stride = std::max<int64_t>(stride, acc_off[i1] - acc_off[i0] + pad); }
+                i0 = i1;
             }
-            if (!big_ri.empty()) {
-                CHK(dgrow(c, c->d_big_ri, big_ri.size(), 0));
-                CHK(dgrow(c, c->d_big_off, big_off.size(), 0));
-                CHK(dgrow(c, c->d_sk_ts, (size_t)big_off.back(), 0));
-                CHK(dgrow(c, c->d_sk_k8, (size_t)big_off.back(), 0));
-                CHK(dgrow(c, c->d_sk_ev, (size_t)big_off.back(), 0));
-                // (pageable sources: the copies are staged before the call returns)
-                HIPCHK(c, hipMemcpyAsync(c->d_big_ri.p, big_ri.data(), big_ri.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(c, hipMemcpyAsync(c->d_big_off.p, big_off.data(), big_off.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-                hipLaunchKernelGGL(k_order_sort_big, dim3((unsigned)big_ri.size()), dim3(1024), 0, c->stream, (const int*)c->d_big_ri.p,
-                                   (const long long*)c->d_big_off.p, (const int*)c->d_acc_ev.p, (const long long*)c->d_acc_off.p,
-                                   (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p, (const unsigned char*)c->d_white.p,
-                                   c->d_sk_ts.p, c->d_sk_k8.p, c->d_sk_ev.p, c->d_sorted.p, c->d_hostflag.p);
+            // the planes of the members sit `stride` entries apart and are read / written at the same offsets at the same
+            // time: 4 KB x odd + 256 B between them, so that they spread over the memory channels whatever the interleaving
+            // granule (a power of two — 131 072 entries for a full slab — put all 256 planes' lines on one channel)
+            stride = (((stride + 1023) >> 10) | 1) * 1024 + 64;
+            const bool two = groups.size() > 1 && !getenv("SW_ORDER_ONE_STREAM");
+            CHK(dgrow(c, c->d_fd, (size_t)stride * n * (two ? 2 : 1), 0));
+            CHK(dgrow(c, c->d_grp, (OrderGroup::ints(np) + 2) * std::max<size_t>(groups.size(), 1), 0));
+            int32_t* d_gbounds = c->d_grp.p + OrderGroup::ints(np) * groups.size();
+            CHK(ensure_order_stage(c, groups.size() * 2));
+            for (size_t gi = 0; gi < groups.size(); ++gi) { c->h_ord_stage[2 * gi] = groups[gi].i0; c->h_ord_stage[2 * gi + 1] = groups[gi].i1; }
+            HIPCHK(c, hipMemcpyAsync(d_gbounds, c->h_ord_stage, groups.size() * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_order_group, dim3((unsigned)groups.size()), dim3(np), 0, c->stream, (const int*)c->d_ordat.p, (const int*)c->d_fwm.p,
+                               (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, (const int*)d_gbounds, n, np, P, c->d_grp.p);
+            c->ctr.kernel_launches++;
+            constexpr int CW = NW >= 4 ? 256 : 64 * NW;
+            const int ncg = np / CW;
+            int S = getenv("SW_ORDER_S") ? atoi(getenv("SW_ORDER_S")) : (1024 + n * ncg - 1) / (n * ncg);
+            S = std::min(std::max(S, 1), 64);
+            if (two) {
+                if (!c->stream_ord) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_ord, hipStreamNonBlocking));
+                for (auto& st : c->stream_srt) if (!st) HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                while (c->ord_events.size() < 3 * groups.size() + 3) {
+                    hipEvent_t e;
+                    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    c->ord_events.push_back(e);
+                }
+            }
+            hipStream_t s1 = two ? c->stream_ord : c->stream;
+            lap("group");
+            CHK(consumer_preamble(s1));   // (the tables it reads are complete: the host has waited for them)
+            if (dbg) { (void)hipStreamSynchronize(s1); lap("preamble"); }
+            {   // timestamps in chain order from the position in front of every member's first unordered event on
+                CHK(dgrow(c, c->d_tch, c->d_chain_ev.cap, 0));
+                int longest = 1;
+                for (int m = 0; m < n; ++m) longest = std::max(longest, c->nev[m] - c->ord_pos[m] + 1);
+                hipLaunchKernelGGL(k_order_tchain, dim3(n, (unsigned)std::min(64, (longest + 255) / 256)), dim3(256), 0, s1, (const int*)c->d_chain_start.p,
+                                   (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, (const int*)c->d_ordpos.p, (const double*)c->d_t.p, c->d_tch.p);
                 c->ctr.kernel_launches++;
-                HIPCHK(c, hipStreamSynchronize(c->stream));   // (big_ri / big_off are locals)
             }
+            for (size_t gi = 0; gi < groups.size(); ++gi) {
+                const Group& g = groups[gi];
+                int* grp = c->d_grp.p + OrderGroup::ints(np) * gi;
+                int* fd = c->d_fd.p + (two && (gi & 1) ? (size_t)stride * n : 0);
+                const int64_t a0 = acc_off[g.i0], na = acc_off[g.i1] - a0;
+                if (two && gi >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ord_events[3 * (gi - 2) + 1], 0));   // the slab's last reader
+                hipLaunchKernelGGL(k_order_walk<CW>, dim3((unsigned)((size_t)n * ncg * S)), dim3(CW), 0, c->stream, (const int*)c->d_L.p,
+                                   (const int*)c->d_seq.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p, (const int*)c->d_ordat.p,
+                                   g.i0, g.i1, (const int*)grp, np, S, P, (long long)stride, fd);
+                if (dbg) { (void)hipStreamSynchronize(s1); lap("walk"); }
+                if (two) {
+                    HIPCHK(c, hipEventRecord(c->ord_events[3 * gi], c->stream));
+                    HIPCHK(c, hipStreamWaitEvent(s1, c->ord_events[3 * gi], 0));
+                }
+                hipLaunchKernelGGL((k_order_median<NW, P>), dim3((unsigned)(na / P + n)), dim3(256), 0, s1, (const int*)fd,
+                                   (long long)stride, (const int*)grp, (const int*)c->d_ordat.p, g.i0, g.i1, n, (const int*)d_fwseq,
+                                   (const long long*)d_acc_off, (const int*)d_seg_off, (const int*)c->d_chain_start.p, (const double*)c->d_tch.p,
+                                   c->d_ts.p, d_info);
+                if (dbg) { (void)hipStreamSynchronize(s1); lap("median"); }
+                hipStream_t s2 = s1;
+                if (two) {
+                    HIPCHK(c, hipEventRecord(c->ord_events[3 * gi + 1], s1));
+                    s2 = c->stream_srt[gi & 1];
+                    HIPCHK(c, hipStreamWaitEvent(s2, c->ord_events[3 * gi + 1], 0));
+                }
+                c->ctr.kernel_launches += 2;
+                CHK(sort_and_fetch(s2, g.i0, g.i1, fetch_early));
+                if (two && fetch_early) HIPCHK(c, hipEventRecord(c->ord_events[3 * gi + 2], s2));
+            }
+            // (round entries that order nothing keep their zeroed flag and have nothing to sort)
+            if (two) {   // the side streams join the main one
+                hipStream_t side[3] = {c->stream_ord, c->stream_srt[0], c->stream_srt[1]};
+                for (int k = 0; k < 3; ++k) {
+                    hipEvent_t e = c->ord_events[3 * groups.size() + k];
+                    HIPCHK(c, hipEventRecord(e, side[k]));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+                }
+            }
+            if (two && fetch_early && out_events && !getenv("SW_ORDER_HOST")) {
+                // the caller's copy of the order, group by group as it arrives, while the device works on the later groups
+                for (size_t gi = 0; gi < groups.size(); ++gi) {
+                    HIPCHK(c, hipEventSynchronize(c->ord_events[3 * gi + 2]));
+                    const int64_t a0 = acc_off[groups[gi].i0], a1 = std::min<int64_t>(acc_off[groups[gi].i1], cap);
+                    if (a1 > a0) memcpy(out_events + a0, sorted + a0, (size_t)(a1 - a0) * sizeof(int32_t));
+                }
+                copied_early_ok = true;
+            }
+            lap("walk+median");
+        } else {
+            CHK(consumer_preamble(c->stream));
+            if constexpr (NW <= 8) {
+                hipLaunchKernelGGL(k_order_times<NW>, dim3((unsigned)((n_acc + 3) / 4)), dim3(256), 0, c->stream,
+                                   (const int*)c->d_acc_ev.p, (const int*)c->d_acc_ri.p, (int)n_acc, (const int*)c->d_fwm.p,
+                                   (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_seq.p,
+                                   (const double*)c->d_t.p, (const int*)c->d_chain_start.p, (const int*)c->d_chain_ev.p,
+                                   (const int*)c->d_ordpos.p, c->d_ts.p, d_info);
+                c->ctr.kernel_launches++;
+            }
+            CHK(sort_and_fetch(c->stream, 0, nr, fetch_early));
+        }
+        if (!big_ri.empty()) {
+            CHK(dgrow(c, c->d_big_ri, big_ri.size(), 0));
+            CHK(dgrow(c, c->d_big_off, big_off.size(), 0));
+            CHK(dgrow(c, c->d_sk_ts, (size_t)big_off.back(), 0));
+            CHK(dgrow(c, c->d_sk_k8, (size_t)big_off.back(), 0));
+            CHK(dgrow(c, c->d_sk_ev, (size_t)big_off.back(), 0));
+            // (pageable sources: the copies are staged before the call returns)
+            HIPCHK(c, hipMemcpyAsync(c->d_big_ri.p, big_ri.data(), big_ri.size() * sizeof(int32_t), hipMemcpyHostToDevice, tail));
+            HIPCHK(c, hipMemcpyAsync(c->d_big_off.p, big_off.data(), big_off.size() * sizeof(long long), hipMemcpyHostToDevice, tail));
+            hipLaunchKernelGGL(k_order_sort_big, dim3((unsigned)big_ri.size()), dim3(1024), 0, tail, (const int*)c->d_big_ri.p,
+                               (const long long*)c->d_big_off.p, (const int*)c->d_acc_ev.p, (const long long*)d_acc_off,
+                               (const double*)c->d_ts.p, (const unsigned char*)c->d_sig.p, (const unsigned char*)c->d_white.p,
+                               c->d_sk_ts.p, c->d_sk_k8.p, c->d_sk_ev.p, c->d_sorted.p, c->d_hostflag.p);
+            c->ctr.kernel_launches++;
+            HIPCHK(c, hipMemcpyAsync(sorted, c->d_sorted.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, tail));
         }
         lap("sort kernels");
-        int err = 0;
-        HIPCHK(c, hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(sorted, c->d_sorted.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hostflag.data(), c->d_hostflag.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_ord + h_blk_off, d_info, sizeof(OrderInfo), hipMemcpyDeviceToHost, tail));
+        HIPCHK(c, hipMemcpyAsync(hostflag, c->d_hostflag.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost, tail));
+        HIPCHK(c, hipStreamSynchronize(tail));
         HIPCHK(c, hipGetLastError());
-        if (err) {
+        if (h_info->index_err) {
             c->transactions.resize(tx_at);   // nothing of this call is kept
             return fail(c, SW_ERANGE, "find_order: an event is seen by a single famous witness (IndexError at swirld.py:305)");
         }
         bool any_flag = false;
-        if (getenv("SW_ORDER_HOST")) std::fill(hostflag.begin(), hostflag.end(), 1);  // test hook: host sort
+        if (getenv("SW_ORDER_HOST")) std::fill(hostflag, hostflag + nr, 1);  // test hook: host sort
         for (int i = 0; i < nr; ++i) { any_flag = any_flag || hostflag[i]; c->ctr.order_rounds_host_sorted += hostflag[i] ? 1 : 0; }
-        if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts and the signatures
+        any_host_sorted = any_flag;
+        if (any_flag) {  // rare: oversize round or a (ts, 8-byte key) tie: the host needs ts, the whitening keys and the signatures
             acc_ev.resize((size_t)n_acc);
             ts.resize((size_t)n_acc);
+            white_h.resize((size_t)nr * 64);
             HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_ts.p, n_acc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(acc_ev.data(), c->d_acc_ev.p, n_acc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(white_h.data(), c->d_white.p, white_h.size(), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             CHK(ensure_sig_h(c));
         }
     }
-    lap("times+sort");
+    lap("read-back");
     // final order inside each round: (consensus timestamp, whitened signature), swirld.py:306
     struct Item { double ts; uint64_t k8; int32_t ev; };
     int64_t produced = 0;
     std::vector<Item> items;
     for (int i = 0; i < nr; ++i) {
-        if (!hostflag[i]) {  // sorted on the device: already in `transactions`
+        if (!n_acc || !hostflag[i]) {  // sorted on the device: already in `transactions`
             produced += acc_off[i + 1] - acc_off[i];
             continue;
         }
-        unsigned char white[64] = {0};  // swirld.py:285
-        for (int j = fw_off[i]; j < fw_off[i + 1]; ++j)
-            for (int b = 0; b < 64; ++b) white[b] ^= c->sig_h[(size_t)fw_ev[j] * 64 + b];
+        const unsigned char* white = white_h.data() + (size_t)i * 64;  // swirld.py:285
         items.clear();
         for (int64_t a = acc_off[i]; a < acc_off[i + 1]; ++a) {
             Item it{ts[a], 0, acc_ev[a]};
@@ -2113,14 +2212,15 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         });
         for (const Item& it : items) sorted[produced++] = it.ev;   // swirld.py:307-309
     }
-    if (out_events && n_acc) memcpy(out_events, sorted, (size_t)std::min<int64_t>(n_acc, cap) * sizeof(int32_t));
+    if (out_events && n_acc && !(copied_early_ok && !any_host_sorted)) memcpy(out_events, sorted, (size_t)std::min<int64_t>(n_acc, cap) * sizeof(int32_t));
     lap("sort");
-    c->ord_pos.swap(ord);
+    std::copy(h_ordnew, h_ordnew + n, c->ord_pos.begin());
     CHK(window_evict(c));
     if (n_out) *n_out = produced;
     if (produced > cap) return fail(c, SW_ERANGE, "find_order: out_events capacity %lld < %lld", (long long)cap, (long long)produced);
     return SW_OK;
 }
+
 
 }  // namespace
 
@@ -2408,10 +2508,17 @@ int sw_destroy(sw_ctx* c) {
     for (hipEvent_t e : c->shot_events) (void)hipEventDestroy(e);
     if (c->h_fame) (void)hipHostFree(c->h_fame);
     if (c->d_err) (void)hipFree(c->d_err);
-    dfree(c->d_fw_ev); dfree(c->d_fw_off); dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
-    dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_acc_off); dfree(c->d_white);
+    dfree(c->d_ord_rounds); dfree(c->d_fwm); dfree(c->d_ordat); dfree(c->d_rowsum); dfree(c->d_grp); dfree(c->d_oblk);
+    if (c->h_ord) (void)hipHostFree(c->h_ord);
+    if (c->h_ord_stage) (void)hipHostFree(c->h_ord_stage);
+    c->transactions.release();
+    if (c->stream_ord) (void)hipStreamDestroy(c->stream_ord);
+    for (auto st : c->stream_srt) if (st) (void)hipStreamDestroy(st);
+    for (auto e : c->ord_events) (void)hipEventDestroy(e);
+    dfree(c->d_q); dfree(c->d_acc_ev); dfree(c->d_acc_ri); dfree(c->d_ts);
+    dfree(c->d_sorted); dfree(c->d_hostflag); dfree(c->d_white);
     dfree(c->d_big_ri); dfree(c->d_sk_ev); dfree(c->d_big_off); dfree(c->d_sk_ts); dfree(c->d_sk_k8);
-    dfree(c->d_fw_cr); dfree(c->d_fd); dfree(c->d_ordhi); dfree(c->d_seg);
+    dfree(c->d_fd); dfree(c->d_seg); dfree(c->d_tch);
     dfree(c->d_rbnd); dfree(c->d_rcuts);
     if (c->d_rprov) (void)hipFree(c->d_rprov);
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
@@ -2682,7 +2789,7 @@ int exact_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, int
         return fail(c, SW_EINVAL, "find_order: a round has an undecided witness (KeyError on self.famous[w], swirld.py:284)");
     const int64_t produced = hdr[swx::H_NOUT];
     const size_t at = c->transactions.size();
-    c->transactions.resize(at + (size_t)produced);
+    if (!c->transactions.resize(at + (size_t)produced)) return fail(c, SW_ENOMEM, "pinned host memory for the ordered events");
     if (produced) {
         HIPCHK(c, hipMemcpyAsync(c->transactions.data() + at, c->x_items_ev.p, (size_t)produced * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

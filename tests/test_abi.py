@@ -98,14 +98,19 @@ def test_committed_measurement_fixtures_bench_reads():
     from conftest import ROOT
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         tr = json.load(f)
-    assert tr["commit"] and tr["kernels"]["k_cansee_chunks"] > 0 and tr["kernels"]["k_tally_tree"] > 0
+    # keyed by workload (the 256 x 1 M figures were quoted for every workload): the default workload of
+    # bench.py must be there, with the sweep's and the loop kernels' bytes and rocprofv3's own launch durations
+    w = tr["workloads"]["256x1000000x0"]
+    assert w["commit"] and w["kernels"]["k_cansee_chunks"] > 0 and w["kernels"]["k_tally_tree"] > 0 and w["avg_us"]["k_cansee_chunks"] > 0
     # the counter passes must have been taken on THIS tree's kernels: the file carries the SHA-256 of
-    # csrc/kernels.hip.h it was measured on; bench.py quotes nothing from a stale file, and this test says so loudly
-    import hashlib
-    with open(os.path.join(ROOT, "py-swirld_amd", "csrc", "kernels.hip.h"), "rb") as f:
-        now = hashlib.sha256(f.read()).hexdigest()
-    assert tr.get("kernels_sha256") == now, ("profiles/traffic.json was measured on other kernel source (commit %s): "
-                                             "run profiles/run_profiles.sh on the GPU box and copy its traffic.json" % tr["commit"])
+    # csrc/kernels.hip.h + csrc/order.hip.h it was measured on; bench.py quotes nothing from a stale file, and this test says so loudly
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_sha", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert tr.get("kernels_sha256") == bench.kernels_sha256(), ("profiles/traffic.json was measured on other kernel source (commit %s): "
+                                                               "run profiles/run_profiles.sh on the GPU box and copy its traffic.json" % w["commit"])
+    assert bench.load_traffic("256x1000000x0")[0] and not bench.load_traffic("1024x123x0")[0], "a workload without a counter pass gets no figures"
     with open(os.path.join(ROOT, "profiles", "reference_python_timing.json")) as f:
         rp = json.load(f)
     assert rp["reference_equals_oracle_on_this_prefix"] is True and rp["members"] == 256 and rp["events_per_s"] > 0

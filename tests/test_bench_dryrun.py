@@ -90,6 +90,9 @@ def test_bench_prints_the_contract_line(pkg, monkeypatch, capsys):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernels", "path_frac", "hbm_bytes_per_step_pmc", "traffic_stale"):
         assert k in r, k
     assert r["traffic_stale"] is False                       # (profiles/traffic.json belongs to this tree's kernel source)
+    assert r["frac"] == r["path_frac"] and r["bound"] == "hbm"   # the headline fraction is the whole path's
+    assert r["traffic"] is None and "none" in r["traffic_source"]   # (no counter pass exists for a 16-member workload: nothing is quoted)
+    assert r["dominant_kernel"]["served_by"].startswith("hbm")    # an L2-served family is never the kernel named under bound "hbm"
     assert {"k_resolve_band", "k_tally_bits", "k_elections"} <= {k["kernel"] for k in r["kernels"]}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c

@@ -34,6 +34,7 @@ def test_find_order_matches_reference_golden(pkg, name, bulk, monkeypatch):
 @pytest.mark.parametrize("n,N,seed,mode,p0,p1,chunk", [
     (4, 4000, 81, 0, 0, 0, 9), (16, 12000, 82, 2, 0.25, 0.03, 500), (64, 40000, 83, 0, 0, 0, None),
     (64, 20000, 84, 3, 0.6, 0, 3000), (130, 20000, 85, 0, 0, 0, None), (256, 30000, 86, 0, 0, 0, 10000),
+    (400, 24000, 87, 0, 0, 0, None), (1024, 40000, 88, 1, 0.5, 0.02, None),   # 8 and 16 mask words: the wide forms of every find_order kernel
 ])
 @pytest.mark.parametrize("bulk", ["default", "1", "0"])   # default threshold, always the table, always the searches
 def test_find_order_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk, bulk, monkeypatch):
