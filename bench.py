@@ -364,7 +364,8 @@ def main():
     ordered = h.find_order(new_c_prof)   # N1 (outside the metric): reported for information only
     find_order_first_ms = (time.perf_counter() - t_fo) * 1e3   # first call of the context: allocates its buffers, fetches the chain pool
     fo_ms = []
-    for _ in range(3):                     # the same call again on the same context, three times: what a running node pays
+    for _ in range(5):                     # the same call again on the same context, five times: what a running node pays (the first two after the
+                                           # buffers were allocated run ~0.8 ms slower than the ones behind them, every time: all five are in the line)
         h.rewind()
         h.divide_rounds(0, N)
         nc2 = h.decide_fame()
@@ -373,7 +374,7 @@ def main():
         ordered2 = h.find_order(nc2)
         fo_ms.append((time.perf_counter() - t_fo) * 1e3)
         assert np.array_equal(ordered, ordered2)
-    find_order_ms = sorted(fo_ms)[1]       # the median of the three
+    find_order_ms = sorted(fo_ms)[2]       # the median of the five
     cd = {k: c1[k] - c0[k] for k in c1}
     wkey = workload_key(n, N, args.mode, args.p0, args.p1)
     traffic, rocprof_us, traffic_commit, traffic_workload, traffic_stale = load_traffic(wkey)

@@ -13,7 +13,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 h = pkg.Hashgraph(n)
 h.reserve(N)
 h.append_events(*pkg.synth_hashgraph(n, N, 3))
-for i in range(4):
+for i in range(int(os.environ.get("ORDER_CALLS", "4"))):
     h.rewind()
     h.divide_rounds(0, N)
     nc = h.decide_fame()

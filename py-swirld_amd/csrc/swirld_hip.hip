@@ -2103,8 +2103,10 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
                 hipStream_t s2 = s1;
                 if (two) {
                     HIPCHK(c, hipEventRecord(c->ord_events[3 * gi + 1], s1));
-                    s2 = c->stream_srt[gi & 1];
-                    HIPCHK(c, hipStreamWaitEvent(s2, c->ord_events[3 * gi + 1], 0));
+                    if (!getenv("SW_ORDER_SORT_INLINE")) {
+                        s2 = c->stream_srt[gi & 1];
+                        HIPCHK(c, hipStreamWaitEvent(s2, c->ord_events[3 * gi + 1], 0));
+                    }
                 }
                 c->ctr.kernel_launches += 2;
                 CHK(sort_and_fetch(s2, g.i0, g.i1, fetch_early));
@@ -2119,7 +2121,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
                     HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
                 }
             }
-            if (two && fetch_early && out_events && !getenv("SW_ORDER_HOST")) {
+            if (two && fetch_early && out_events && !getenv("SW_ORDER_HOST") && !getenv("SW_ORDER_LATE_COPY")) {
                 // the caller's copy of the order, group by group as it arrives, while the device works on the later groups
                 for (size_t gi = 0; gi < groups.size(); ++gi) {
                     HIPCHK(c, hipEventSynchronize(c->ord_events[3 * gi + 2]));
