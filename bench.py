@@ -178,6 +178,60 @@ def strong_section(args, pkg, part_mod, rep, torch, rank, local_rank, world, n, 
                   "what": "sw_rewind + StrongSplit.divide_rounds (range sweeps, %d async broadcasts of int32 rows, replicated round loop) + "
                           "candidate-partitioned decide_fame (one all-reduce), max over ranks" % world}
         hs.close()
+    elif npad_of(n) > 256 and (world > 1 or args.emulate_parts > 1):
+        # Beyond 256 members the split is INSIDE the iterations of the round loop (include/swirld_hip.h part 3): the band events and
+        # the members of an iteration are dealt to the parts, which store into each other's tables (peer-mapped memory) and meet
+        # at the two kernel boundaries.  The parts are contexts of ONE process — rank 0 drives one context per GPU of the node
+        # from one host thread each; the other ranks wait at the barrier (world == 1: --emulate-parts contexts on the one GPU, a
+        # functional run).
+        P = world if world > 1 else args.emulate_parts
+        spread = world > 1 and torch.cuda.device_count() >= P
+        devs = list(range(P)) if spread else [local_rank] * P
+        if rank == 0:
+            s_stream = pkg.synth_hashgraph(n, N, args.seed, args.mode, args.p0, args.p1)
+            hp = []
+            for d in devs:
+                h_ = pkg.Hashgraph(n, device=d)
+                h_.reserve(N)
+                h_.append_events(*s_stream)
+                hp.append(h_)
+            pkg.Hashgraph.split_link(hp)
+            gate = threading.Barrier(P)
+            res = [None] * P
+
+            def part_steps(i, k):
+                for _ in range(k):
+                    hp[i].rewind()
+                    hp[i].synchronize()
+                    gate.wait()          # (a part's first band kernel stores into the others' tables: nobody divides before everybody has rewound)
+                    hp[i].divide_rounds(0, N)
+                    res[i] = [int(r) for r in hp[i].decide_fame()]
+
+            def all_parts(k):
+                ths = [threading.Thread(target=part_steps, args=(i, k)) for i in range(P)]
+                for t_ in ths:
+                    t_.start()
+                for t_ in ths:
+                    t_.join()
+
+            all_parts(max(1, args.warmup))
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            all_parts(args.steps)
+            dts = time.perf_counter() - ts0
+            assert all(r == res[0] for r in res) and res[0] == [int(r) for r in new_c], "every part ends with the replicas' new_c"
+            strong = {"events_per_s": round(N * args.steps / dts, 1), "ms_per_step": round(dts / args.steps * 1e3, 3), "parts": P,
+                      "devices": devs, "one_gpu_per_part": bool(spread), "new_c_last_step": len(res[0]),
+                      "round_iterations_all_steps": int(hp[0].counters()["round_iterations"]),
+                      "what": "sw_rewind + sw_divide_rounds on %d linked contexts (sw_split_link: band events and members of every iteration dealt "
+                              "to the parts, peer stores, event meetings at both kernel boundaries; sweep and elections replicated) + sw_decide_fame, "
+                              "driven by rank 0, one host thread per part" % P}
+            if not spread:
+                strong["note"] = ("functional run: the parts share ONE device, their kernels take turns on it — not a multi-GPU figure; "
+                                  "profiles/r06_split_pieces_1024x2M.txt has what one part runs per iteration alone on a GPU")
+            for h_ in hp:
+                h_.close()
+        barrier()
     elif world == 1 and args.emulate_parts > 1 and npad_of(n) <= 256:
         dev = torch.device("cuda", local_rank)
         P = args.emulate_parts

@@ -147,6 +147,27 @@ int sw_import_rows(sw_ctx* ctx, int64_t first, int64_t K, const void* src_device
 int sw_get_range_stats(sw_ctx* ctx, int64_t* provisional, int64_t* repaired, int64_t* resweeps);
 
 /*
+ * Multi-GPU building block, part 3 (last bullet; no reference counterpart): ONE hashgraph's ROUND LOOP over
+ * `parts` linked contexts — one per GPU of this process, or several on one GPU — split INSIDE an iteration (swirld.py:208-216
+ * once per candidate event): the band events whose threshold masks an iteration builds, and the members whose candidate
+ * windows it tallies, are dealt to the parts; every part stores what it produces (mask rows and popcounts, round numbers and
+ * sees-masks of the band events, its members' verdict words) into the tables of EVERY part through peer-mapped device memory
+ * (plain stores and atomics over xGMI: no collective inside an iteration), and the parts' streams meet at the iteration's two
+ * kernel boundaries through events.  Everything else of sw_divide_rounds stays replicated: each part holds the whole hashgraph
+ * and sweeps the whole can_see table.
+ *   sw_split_link    links `parts` (2 .. 8) contexts that hold the SAME events (same sw_append_events calls) and are divided up
+ *                    to the same point; peer access between their devices is enabled.  Unit stake only (SW_ENOTSUP otherwise);
+ *                    not on the exact (forked) path, not with the windowed table.
+ *   afterwards       EVERY part calls sw_divide_rounds with the same arguments, each from its own host thread (the calls meet
+ *                    iteration by iteration; a part that never arrives makes the others fail with SW_EIO after 30 s);
+ *                    sw_decide_fame / sw_find_order / getters per context as usual — each part ends with the complete state.
+ *   sw_split_unlink  dissolves the group (also done by sw_destroy of any of its contexts).
+ * Results are those of an unlinked context (tests/test_gpu_split_loop.py: parts on one GPU against the oracle).
+ */
+int sw_split_link(sw_ctx* const* ctxs, int parts);
+int sw_split_unlink(sw_ctx* ctx);
+
+/*
  * Node.find_order(new_c) (swirld.py:280-311) for the given rounds (processed in
  * ascending order like sorted(new_c)).  Appends to the internal `transactions` list
  * and writes the newly ordered event indices, in final order, to out_events.

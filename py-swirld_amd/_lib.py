@@ -50,6 +50,8 @@ SIGNATURES = {
     "sw_row_stride": (C.c_int, [_P]),
     "sw_get_tally_impl": (C.c_int, [_P]),
     "sw_cansee_range": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "sw_split_link": (C.c_int, [_P, C.c_int]),
+    "sw_split_unlink": (C.c_int, [_P]),
     "sw_cansee_repair": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "sw_export_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "sw_import_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),

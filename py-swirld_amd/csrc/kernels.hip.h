@@ -1013,6 +1013,23 @@ struct LoopBufs {
     int dbg_minor;    // ... 1: every phase of the resolve step is stamped (each stamp drains the wave: SW_DEBUG_CLOCKS=2 keeps only entry / band start / end)
 };
 
+// ONE hashgraph's round loop over `parts` linked contexts (one per GPU): the replicated resolve step runs in
+// every context, the band events and the members are DEALT to the parts, and what a part produces — the band events' mask
+// rows and popcounts, their round numbers and sees-masks, its members' verdict words — is stored into the tables of EVERY
+// part (peer-mapped device memory: plain stores and atomics over xGMI, no collective inside an iteration).  The contexts'
+// streams meet at the two kernel boundaries of an iteration (events; swirld_hip.hip, enqueue_iteration).
+#define SW_MAX_PARTS 8
+struct SplitDst {
+    int part, parts;              // this part's share: band groups / members part, part + parts, ...
+    int ndst;                     // tables stored to: `parts` (1 when ONE context plays the parts one behind the other: SW_SPLIT_EMULATE)
+    u64* Mb[SW_MAX_PARTS];        // row 1 of every part's band-mask table
+    int* Pc[SW_MAX_PARTS];        // ... and of its popcounts
+    u64* S[SW_MAX_PARTS];         // sees-masks
+    int* round[SW_MAX_PARTS];     // round numbers
+    u64* found64[SW_MAX_PARTS];   // verdict words of the tally
+    int* farslot[SW_MAX_PARTS];
+};
+
 // Kernel arguments are fetched lazily by the compiler (an s_load right before the first use, one
 // per 64-byte line of the kernarg segment), and every such fetch is a dependent scalar-cache miss
 // in the middle of a latency-bound kernel.  Pinning makes all of them arrive with the first one.
@@ -1088,13 +1105,14 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
 // has work, derive the band.  Step 2: threshold masks of the band events, Mb[k-mlo] bit c_ =
 // (L[k][c_] >= lo[r][c_]) = "the latest event of c_ that k sees has round >= r" (one wave per
 // band event, NW ballots).
-template <int NW, bool FAST>
+template <int NW, bool FAST, bool SPLIT = false>
 __global__ void __launch_bounds__(1024)
 k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip, int NEARCAP, int MCAP, int Rcap,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
                const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb,
-               int* __restrict__ round_out, u64* __restrict__ S_out, int* __restrict__ Pc) {
+               int* __restrict__ round_out, u64* __restrict__ S_out, int* __restrict__ Pc, SplitDst sd) {
+    static_assert(!(FAST && SPLIT), "the split form takes the generic band path");
     __shared__ int s_red[2][4][16];  // [parity][quantity][wave]: per-wave partial results
     __shared__ int s_thr[1024];
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
@@ -1485,8 +1503,9 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
     // share of the band, so that the kernel ends with the band and not with its stores
     const int skipw = gridDim.x > 1 ? 1 : 0;
     if (skipw && writer) { flush_cand(); return; }
-    const int wave = (blockIdx.x - skipw) * wpb + (threadIdx.x >> 6);
-    const int nwaves = (gridDim.x - skipw) * wpb;
+    // (split: the groups of band events are dealt to the parts — wave w of part p is wave w * parts + p of the whole)
+    const int wave = SPLIT ? ((blockIdx.x - skipw) * wpb + (threadIdx.x >> 6)) * sd.parts + sd.part : (blockIdx.x - skipw) * wpb + (threadIdx.x >> 6);
+    const int nwaves = SPLIT ? (gridDim.x - skipw) * wpb * sd.parts : (gridDim.x - skipw) * wpb;
     int t_[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) t_[j] = s_thr[j * 64 + lane];
@@ -1584,11 +1603,23 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                         word = lane == j ? bm : word;
                         pcs += __popcll(bm);
                     }
+                    if constexpr (SPLIT) {   // into the tables of every part
+                        const bool fin = (fin_m >> (ks[u] - base)) & 1ull;
+                        for (int q = 0; q < sd.ndst; ++q) {
+                            if (lane < NW) sd.Mb[q][(size_t)(ks[u] - mlo) * NW + lane] = word;
+                            if (lane == NW + 1) sd.Pc[q][ks[u] - mlo] = pcs;
+                            if (fin) {
+                                if (lane < NW) sd.S[q][(size_t)ks[u] * NW + lane] = word;
+                                if (lane == NW) sd.round[q][ks[u]] = r;
+                            }
+                        }
+                    } else {
                     if (lane < NW) Mb[(size_t)(ks[u] - mlo) * NW + lane] = word;
                     if (lane == NW + 1) Pc[ks[u] - mlo] = pcs;
                     if ((fin_m >> (ks[u] - base)) & 1ull) {
                         if (lane < NW) S_out[(size_t)ks[u] * NW + lane] = word;
                         if (lane == NW) round_out[ks[u]] = r;
+                    }
                     }
                 }
         }
@@ -1944,13 +1975,13 @@ __device__ __forceinline__ uint32_t bits_finish(uint32_t (&b)[ilog2_c(64 * NW) +
 // below that the candidate FAILS without a gather; a failing one has at most t columns above t, each at most V, the others at
 // most t, hence S <= t V + (n - t) t — above that it PASSES without a gather.  On uniform gossip the two bounds leave ~4 of a
 // member's slots for the exact count (tests/model_bulk.py `popcount_bounds`); every verdict is still exact.
-template <int NW, bool FILT>
+template <int NW, bool FILT, bool SPLIT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 4 ? 8 : 2, 8)))
 k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
              const int* __restrict__ chain_ev,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-             const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad, const int* __restrict__ Pc) {
+             const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad, const int* __restrict__ Pc, SplitDst sd) {
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
     constexpr int G = 64 / W32;          // hop groups
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad
@@ -1967,7 +1998,11 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     const int lane = lane_id();
     const int wib = threadIdx.x >> 6;
     const int wv = blockIdx.x * 4 + wib;
-    const int cm = wv / K, cj = wv - cm * K;  // member, candidate slot
+    // member, candidate slot (split: this part tallies the members part, part + parts, ...; a wave beyond the last of them
+    // takes the path of a member that is not searching)
+    const int cm_raw = SPLIT ? sd.part + sd.parts * (wv / K) : wv / K;
+    const bool cm_ok = !SPLIT || cm_raw < npad;
+    const int cm = cm_ok ? cm_raw : npad - 1, cj = wv - (wv / K) * K;
     // The verdict of this wave: `key` (its tally passed) or `fark` (a FAR candidate).  Verdicts go to the
     // member's words by atomicMin — ~7000 waves on ~24 cache lines serialise at the memory side (3-5 us
     // of kernel tail, measured with the phase stamps); the four waves of a workgroup are (mostly) four
@@ -1985,7 +2020,7 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
     // one 128-byte line per lane while they wait for their own first round trips (SW_TALLY_PF=0 switches it
     // off): 7.76 -> 7.69 ms per pass at 256 members / 1 M events.
     // (the member's words are requested BEFORE the touch below: see k_tally_tree)
-    const int un = B.unres[pb + cm], frc = B.force[pb + cm];
+    const int un = cm_ok ? B.unres[pb + cm] : 0, frc = B.force[pb + cm];
     const int* cand = B.cand + ((size_t)(1 - par) * npad + cm) * 64;
     const int e = cand[cj + 1];  // published by k_resolve_band (-1: no such candidate)
     // what the next resolve step will want if this slot is the member's first passing one: the last candidate of
@@ -2099,8 +2134,15 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
                 key = s_key[w2] < key ? s_key[w2] : key;
                 fark = s_fark[w2] < fark ? s_fark[w2] : fark;
             }
+            if constexpr (SPLIT) {   // into the verdict words of every part
+                for (int q = 0; q < sd.ndst; ++q) {   // (system scope: the words of the other parts live on other GPUs)
+                    if (key != ~0ull) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(&sd.found64[q][pb + cm]), (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (fark != SW_INF) __hip_atomic_fetch_min(&sd.farslot[q][pb + cm], fark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            } else {
             if (key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&B.found64[pb + cm]), key);
             if (fark != SW_INF) atomicMin(&B.farslot[pb + cm], fark);
+            }
         }
         if (nfar) atomicAdd(&st->far_hops, nfar);
     }

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -75,8 +76,26 @@ struct VmTable {
     int64_t evictions = 0;
 };
 
+// ONE hashgraph's round loop over several linked contexts (sw_split_link; kernels.hip.h SplitDst): what the host threads of
+// the parts share.  Every part runs its own sw_divide_rounds (same events, same call); inside an iteration of the round loop
+// its stream waits, at both kernel boundaries, for the other parts' kernels of that boundary — an event per (part, boundary,
+// iteration), waited for only after its owner has RECORDED it (`rec`: the producer's packet is then in front of the
+// waiter's wherever the runtime maps the streams).
+struct SplitGroup {
+    int parts = 0;
+    sw_ctx* ctx[SW_MAX_PARTS] = {nullptr};
+    std::atomic<long long> rec[2][SW_MAX_PARTS];   // iterations whose band / tally event the part has recorded
+    std::atomic<int> abort{0};                     // a part failed: the others stop waiting for it
+    hipEvent_t ev[2][SW_MAX_PARTS][64] = {};
+};
+
 struct sw_ctx {
     int n = 0, nw = 0, npad = 0, coin_period = 6, device = 0;
+    SplitGroup* split = nullptr;   // linked with other contexts (sw_split_link)
+    int split_part = 0;
+    long long split_iter = 0;      // iterations of the round loop enqueued since the link
+    bool split_failed = false;     // a meeting of the parts failed (a part gave up): the call reports it
+    int split_emulate = 0;         // SW_SPLIT_EMULATE (measurement): this many parts played by this one context, one behind the other
     VmTable vm;
     int64_t first_resident = 0;   // can_see rows below this event index have been evicted (windowed mode)
     bool vm_scratch_ok = false;   // windowed mode: the halo scratch rows behind row `cap` are mapped (the sweep may run in chunks)
@@ -864,8 +883,119 @@ LoopBufs loop_bufs(sw_ctx* c) {
 // one iteration of the round loop = (resolve + band masks) -> tally; both kernels guard on the
 // device-side state, so extra iterations after `done` are no-ops.  `par` = iteration parity
 // (which half of the double-buffered loop state is read / written).
+// the tables of every part of a split, as the split kernels take them
+SplitDst split_dst(const sw_ctx* c) {
+    SplitDst d{};
+    const SplitGroup* g = c->split;
+    d.part = c->split_part;
+    d.parts = g->parts;
+    d.ndst = g->parts;
+    for (int q = 0; q < g->parts; ++q) {
+        const sw_ctx* o = g->ctx[q];
+        d.Mb[q] = o->d_Mb.p + o->nw;
+        d.Pc[q] = o->d_Pc.p + 1;
+        d.S[q] = o->d_S.p;
+        d.round[q] = o->d_round.p;
+        d.found64[q] = o->d_found64.p;
+        d.farslot[q] = o->d_farslot.p;
+    }
+    return d;
+}
+
+// One boundary of a split iteration: this part's kernel of the boundary is enqueued — record its event, tell the others, and
+// make this part's stream wait for theirs (each waited for only once its owner has recorded it).  false: a part gave up.
+bool split_meet(sw_ctx* c, int which, long long it) {
+    SplitGroup* g = c->split;
+    const int p = c->split_part, slot = (int)(it & 63);
+    if (hipEventRecord(g->ev[which][p][slot], c->stream) != hipSuccess) { g->abort.store(1); return false; }
+    g->rec[which][p].store(it + 1, std::memory_order_release);
+    for (int q = 0; q < g->parts; ++q) {
+        if (q == p) continue;
+        const auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (g->rec[which][q].load(std::memory_order_acquire) < it + 1) {
+            if (g->abort.load()) return false;
+            if ((++spins & 1023) == 0) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { g->abort.store(1); return false; }   // (a part that never entered the call)
+                std::this_thread::yield();
+            }
+        }
+        if (hipStreamWaitEvent(c->stream, g->ev[which][q][slot], 0) != hipSuccess) { g->abort.store(1); return false; }
+    }
+    return true;
+}
+
+// an iteration of a linked context (sw_split_link): its share of the band events, the meeting, its share of the members, the meeting
+template <int NW>
+void enqueue_iteration_split(sw_ctx* c, int par) {
+    const int np = c->npad, K = c->K;
+    const int bt = std::max(np, 256);
+    const uint32_t tot2 = 2u * c->tot;
+    const LoopBufs B = loop_bufs(c);
+    const SplitDst sd = split_dst(c);
+    const long long it = c->split_iter++;
+    hipLaunchKernelGGL((k_resolve_band<NW, false, true>), dim3(c->band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
+                       c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
+                       (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, sd);
+    if (!split_meet(c, 0, it)) { c->split_failed = true; return; }
+    const int members_here = (np - sd.part + sd.parts - 1) / sd.parts;
+    const int tally_blocks = (members_here * K + 3) / 4;
+    auto tally_bits = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, 0,
+                           (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
+                           (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sd);
+    };
+    if (c->tally_filter) tally_bits(k_tally_bits<NW, true, true>);
+    else tally_bits(k_tally_bits<NW, false, true>);
+    if (!split_meet(c, 1, it)) { c->split_failed = true; return; }
+    c->ctr.kernel_launches += 2;
+}
+
+// SW_SPLIT_EMULATE=<parts> (measurement): ONE unlinked context plays the parts of a split one behind the other — the band
+// kernel of every part, then the tally kernel of every part, all storing into its own tables.  Results are those of the plain
+// loop; every launch is exactly what one GPU of a `parts`-GPU node runs per iteration, alone on the chip
+// (profiles/split_pieces.py reads their durations from the kernel trace).
+template <int NW>
+void enqueue_iteration_emulated(sw_ctx* c, int par, int parts) {
+    const int np = c->npad, K = c->K;
+    const int bt = std::max(np, 256);
+    const uint32_t tot2 = 2u * c->tot;
+    const LoopBufs B = loop_bufs(c);
+    SplitDst sd{};
+    sd.parts = parts; sd.ndst = 1;
+    sd.Mb[0] = c->d_Mb.p + NW; sd.Pc[0] = c->d_Pc.p + 1; sd.S[0] = c->d_S.p; sd.round[0] = c->d_round.p;
+    sd.found64[0] = c->d_found64.p; sd.farslot[0] = c->d_farslot.p;
+    for (int q = 0; q < parts; ++q) {
+        sd.part = q;
+        hipLaunchKernelGGL((k_resolve_band<NW, false, true>), dim3(c->band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
+                           c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
+                           (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, sd);
+    }
+    for (int q = 0; q < parts; ++q) {
+        sd.part = q;
+        const int members_here = (np - q + parts - 1) / parts;
+        const int tally_blocks = (members_here * K + 3) / 4;
+        if (c->tally_filter)
+            hipLaunchKernelGGL((k_tally_bits<NW, true, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, 0,
+                               (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
+                               (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
+                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sd);
+        else
+            hipLaunchKernelGGL((k_tally_bits<NW, false, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, 0,
+                               (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
+                               (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
+                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sd);
+    }
+    c->ctr.kernel_launches += 2 * parts;
+}
+
 template <int NW>
 void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::vector<Span>* resolve_spans = nullptr) {
+    if (c->split) { enqueue_iteration_split<NW>(c, par); return; }
+    if (c->split_emulate > 0 && c->unit_stake && c->tally_impl == 1) { enqueue_iteration_emulated<NW>(c, par, c->split_emulate); return; }
     const int np = c->npad, K = c->K;
     const int tally_blocks = np * K / 4;
     const int bt = std::max(np, 256);
@@ -878,7 +1008,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
         hipLaunchKernelGGL(kern, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                            c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                            (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1);
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, SplitDst{});
     };
     if constexpr (NW <= 4) {
         if (c->band_fast) resolve_band(k_resolve_band<NW, true>);
@@ -895,7 +1025,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
             hipLaunchKernelGGL(kern, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, c->tally_pf,
                                (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                                (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p);
+                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, SplitDst{});
         };
         if (c->tally_filter) tally_bits(k_tally_bits<NW, true>);
         else tally_bits(k_tally_bits<NW, false>);
@@ -922,7 +1052,7 @@ constexpr int kGraphSizesBase[4] = {0, 24, 8, 2};
 template <int NW>
 int launch_iterations(sw_ctx* c, int n_iters, std::vector<Span>* tally_spans, std::vector<Span>* resolve_spans = nullptr) {
     // short shots (a Node's small calls): plain launches — the first hipGraphLaunch of a call costs ~200 us
-    if (!c->use_graph || tally_spans || n_iters <= 8) {
+    if (!c->use_graph || tally_spans || n_iters <= 8 || c->split || c->split_emulate) {   // (split: the meetings of the parts are host calls between the kernels)
         for (int it = 0; it < n_iters; ++it) enqueue_iteration<NW>(c, it & 1, tally_spans, resolve_spans);
         return SW_OK;
     }
@@ -1024,7 +1154,8 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     }
     for (;;) {
         CHK(ensure_rounds(c, c->R + launched + shot + 4));
-        CHK(launch_iterations<NW>(c, shot, c->profiling ? &tally_spans : nullptr, c->profiling ? &resolve_spans : nullptr));
+        CHK(launch_iterations<NW>(c, shot, c->profiling && !c->split ? &tally_spans : nullptr, c->profiling && !c->split ? &resolve_spans : nullptr));
+        if (c->split_failed) { c->poisoned = true; return fail(c, SW_EIO, "split round loop: a linked context did not arrive at iteration %lld (sw_split_link: every part calls sw_divide_rounds)", c->split_iter); }
         // host work that is off the critical path (the finalize / witness / voter-mask launches of the PREVIOUS sub-batch, on
         // their own stream) goes here: the GPU is already busy with this sub-batch's first shot
         if (launched == 0 && after_first_shot) CHK((*after_first_shot)());
@@ -2328,6 +2459,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (c->npad > 256) c->tally_filter = 1;
     knob("SW_TALLY_FILTER", 0, 1, &c->tally_filter);
     knob("SW_CHAIN", 0, 1, &c->chain);
+    knob("SW_SPLIT_EMULATE", 0, SW_MAX_PARTS, &c->split_emulate);   // (measurement: the parts of a split played by one context; pin SW_TALLY_IMPL=1 with it)
     knob("SW_BRIDGE", 2, 512, &c->bridge);
     c->bridge &= ~1;
     knob("SW_SHOT_PCT", 10, 400, &c->shot_pct);
@@ -2472,7 +2604,10 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     return SW_OK;
 }
 
+static void split_dissolve(SplitGroup* g);
+
 int sw_destroy(sw_ctx* c) {
+    if (c && c->split) split_dissolve(c->split);
     if (!c) return SW_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
@@ -3508,6 +3643,72 @@ int sw_reset(sw_ctx* c) {
     c->payload_pending = false;
     c->exact = false;  // (a fresh hashgraph starts on the fast path again)
     c->chunks_off = false;  // ... and with the chunked sweep
+    return SW_OK;
+}
+
+static void split_dissolve(SplitGroup* g) {
+    if (!g) return;
+    for (int q = 0; q < g->parts; ++q)
+        if (g->ctx[q]) { (void)hipStreamSynchronize(g->ctx[q]->stream); g->ctx[q]->split = nullptr; }
+    for (int w = 0; w < 2; ++w)
+        for (int q = 0; q < SW_MAX_PARTS; ++q)
+            for (auto e : g->ev[w][q]) if (e) (void)hipEventDestroy(e);
+    delete g;
+}
+
+int sw_split_link(sw_ctx* const* ctxs, int parts) {
+    if (!ctxs || parts < 2 || parts > SW_MAX_PARTS) return fail(nullptr, SW_EINVAL, "sw_split_link: 2 .. %d contexts", SW_MAX_PARTS);
+    sw_ctx* c0 = ctxs[0];
+    for (int q = 0; q < parts; ++q) {
+        sw_ctx* c = ctxs[q];
+        if (!c) return fail(c0, SW_EINVAL, "sw_split_link: context %d is NULL", q);
+        for (int o = 0; o < q; ++o) if (ctxs[o] == c) return fail(c, SW_EINVAL, "sw_split_link: context %d given twice", q);
+        if (c->poisoned) return fail(c, SW_EIO, "context poisoned by an earlier failure");
+        if (c->split) return fail(c, SW_EINVAL, "sw_split_link: context %d is linked already", q);
+        if (c->exact || c->vm.active || !c->unit_stake)
+            return fail(c, SW_ENOTSUP, "sw_split_link: unit stake, the fast path and the plain can_see table only");
+        if (c->n != c0->n || c->N != c0->N || c->divided != c0->divided || c->R != c0->R || c->coin_period != c0->coin_period)
+            return fail(c, SW_EINVAL, "sw_split_link: context %d does not hold the same hashgraph, divided to the same point, as context 0", q);
+        if (c->MCAP != c0->MCAP || c->NEARCAP != c0->NEARCAP || c->skip != c0->skip || c->gallop_after != c0->gallop_after || c->pipe != c0->pipe)
+            return fail(c, SW_EINVAL, "sw_split_link: context %d was created under other tuning knobs than context 0", q);
+    }
+    SplitGroup* g = new SplitGroup();
+    g->parts = parts;
+    for (int w = 0; w < 2; ++w) for (int q = 0; q < SW_MAX_PARTS; ++q) g->rec[w][q].store(0);
+    for (int q = 0; q < parts; ++q) {
+        sw_ctx* c = ctxs[q];
+        g->ctx[q] = c;
+        if (hipSetDevice(c->device) != hipSuccess) { split_dissolve(g); return fail(c0, SW_EIO, "hipSetDevice(%d) failed", c->device); }
+        for (int o = 0; o < parts; ++o)
+            if (ctxs[o]->device != c->device) {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, c->device, ctxs[o]->device);
+                if (!can) { split_dissolve(g); return fail(c0, SW_ENOTSUP, "sw_split_link: device %d cannot map the memory of device %d", c->device, ctxs[o]->device); }
+                const hipError_t e = hipDeviceEnablePeerAccess(ctxs[o]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); split_dissolve(g); return fail(c0, SW_EIO, "hipDeviceEnablePeerAccess failed: %s", hipGetErrorString(e)); }
+                (void)hipGetLastError();
+            }
+        for (int w = 0; w < 2; ++w)
+            for (auto& e : g->ev[w][q])
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { split_dissolve(g); return fail(c0, SW_EIO, "hipEventCreate failed"); }
+    }
+    for (int q = 0; q < parts; ++q) {
+        sw_ctx* c = ctxs[q];
+        // the split kernels exist for the one-wave-per-slot tally (the default beyond 256 members)
+        c->tally_impl = 1; c->tally_auto = false; c->K = c->K_flat; c->K_auto = false;
+        c->chain = 0;
+        c->split_part = q;
+        c->split_iter = 0;
+        c->split_failed = false;
+        c->split = g;
+    }
+    return SW_OK;
+}
+
+int sw_split_unlink(sw_ctx* c) {
+    if (!c) return SW_EINVAL;
+    if (!c->split) return SW_OK;
+    split_dissolve(c->split);
     return SW_OK;
 }
 

@@ -104,6 +104,41 @@ class Hashgraph:
         self._chk(self._L.sw_commit_fame(self._h, _p(fam), _p(dec), R, _p(out), int(out.shape[0]), C.byref(n_new)))
         return out[: n_new.value].copy()
 
+    @staticmethod
+    def split_link(parts):
+        """Link the contexts `parts` (2 .. 8 Hashgraph objects holding the same events, one per GPU or several on one): from now
+        on ONE round loop runs over all of them, split inside its iterations (include/swirld_hip.h, part 3).  Every part then
+        calls divide_rounds with the same arguments from its own thread: `split_divide_rounds` does that."""
+        arr = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        rc = parts[0]._L.sw_split_link(arr, len(parts))
+        if rc != 0:
+            msg = next((m for m in (p._L.sw_last_error(p._h).decode() for p in parts) if m), "") or parts[0]._L.sw_last_error(None).decode()
+            raise SwirldHipError(rc, msg)
+
+    def split_unlink(self):
+        self._chk(self._L.sw_split_unlink(self._h))
+
+    @staticmethod
+    def split_divide_rounds(parts, first, K):
+        """divide_rounds(first, K) on every linked context at once, one host thread per part (the C calls release the GIL and meet
+        iteration by iteration on the device); raises the first part's error."""
+        import threading
+        errs = [None] * len(parts)
+
+        def work(i):
+            try:
+                parts[i].divide_rounds(first, K)
+            except Exception as exc:  # noqa: BLE001
+                errs[i] = exc
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(parts))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+
     def find_order(self, rounds):
         rounds = np.ascontiguousarray(sorted(int(r) for r in rounds), np.int32)
         cap = self.num_events

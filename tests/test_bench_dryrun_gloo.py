@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, hang_rank, timeout_s, q):
+def _worker(rank, world, port, hang_rank, timeout_s, q, members=12, events=3000):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import threading
@@ -46,6 +46,10 @@ def _worker(rank, world, port, hang_rank, timeout_s, q):
         def range_stats(self):
             return 0, 0, 0
 
+        @staticmethod
+        def split_link(parts):      # (the stand-in parts each divide the whole hashgraph: the flow of bench.py is what runs here)
+            assert len({id(p) for p in parts}) == len(parts) >= 2
+
     class DryRange(ModelRangeBackend):
         """the numpy model of the event-range sweep where bench.py would put the host-staged HIP backend"""
         def __init__(self, hs, dev):
@@ -66,7 +70,8 @@ def _worker(rank, world, port, hang_rank, timeout_s, q):
     torch.cuda.is_available = lambda: True
     torch.cuda.set_device = lambda *a, **k: None
     torch.cuda.synchronize = lambda *a, **k: None
-    sys.argv = ["bench.py", "--gpus", str(world), "--backend", "gloo", "--one-device", "--members", "12", "--events", "3000",
+    torch.cuda.device_count = lambda: 1
+    sys.argv = ["bench.py", "--gpus", str(world), "--backend", "gloo", "--one-device", "--members", str(members), "--events", str(events),
                 "--steps", "2", "--warmup", "1", "--contexts", "1", "--concurrent", "0", "--cpu-sample", "0", "--e2e-steps", "1",
                 "--reference-events", "0", "--strong-timeout", str(timeout_s)]
     buf = io.StringIO()
@@ -89,11 +94,11 @@ def _worker(rank, world, port, hang_rank, timeout_s, q):
     q.put((rank, buf.getvalue(), 0))
 
 
-def _run(world, hang_rank, timeout_s):
+def _run(world, hang_rank, timeout_s, members=12, events=3000):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, hang_rank, timeout_s, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, hang_rank, timeout_s, q, members, events)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -116,6 +121,20 @@ def test_two_rank_bench_line_with_the_one_hashgraph_split(pkg):
     s = d["strong"]
     assert s["parts"] == 2 and s["events_per_s"] > 0 and d["value_strong"] == s["events_per_s"] and s["new_c_last_step"] > 0
     assert "replicas x2" in d["config"]["parallelism"]
+
+
+def test_two_rank_bench_line_beyond_256_members_rank_0_drives_the_linked_parts(pkg):
+    """more than 256 members: the split is inside the round loop's iterations (sw_split_link) and its parts are contexts of
+    ONE process — rank 0 links one per rank and drives them from a thread each, rank 1 waits at the barrier; the line carries
+    `value_strong` from that run"""
+    res, codes = _run(2, -1, 240, members=300, events=9000)
+    assert codes == [0, 0]
+    lines = [ln for ln in res[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in res[1][0].splitlines() if ln.startswith("{")]
+    d = json.loads(lines[0])
+    s = d["strong"]
+    assert d["n_gpus"] == 2 and s["parts"] == 2 and s["events_per_s"] > 0 and d["value_strong"] == s["events_per_s"]
+    assert s["one_gpu_per_part"] is False and "sw_split_link" in s["what"] and s["new_c_last_step"] >= 0
 
 
 def test_a_rank_that_never_joins_the_split_costs_value_strong_not_the_line(pkg):
