@@ -1050,34 +1050,9 @@ __device__ __forceinline__ void pin_arg(uint32_t v) { asm volatile("" ::"s"(v));
 
 // Start of a round-loop run: the loop state and the per-member buffers in ONE launch (a small
 // call would otherwise pay five separate copies / fills, ~10 us each).
-// CHAINED start (round 5): the loop of the next sub-batch is enqueued right behind the shot of the running one, without the host
-// round trip in between (read the state, find the start round, launch).  What the host computed then is found here: the previous
-// loop must have reported `done` (an even number of launches leaves its final state in half 0) — if not, this launch REFUSES:
-// it touches nothing, the iterations enqueued behind it go on with the old loop, and the host (which sees the same state in its
-// read-back) starts this loop again the slow way; the exhaustion marks are in the half the previous loop's iteration count
-// names; the start round is the smallest front round among the members this sub-batch adds events to (their visible chain
-// grows), else the last round.  A sub-batch that holds a member's first event is never chained (its root row comes from the host).
 __global__ void __launch_bounds__(1024)
 k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __restrict__ visible_len, int* chain_len, int eval_src, int fin_from,
-            int chained, int prev_N) {
-    __shared__ int s_min[16];
-    if (chained) {
-        const RState* pv = B.st;
-        if (!pv->done || pv->err || pv->N != prev_N) return;   // refused (uniform over the workgroup)
-        eval_src = pv->iter & 1;
-        const int last_round = pv->max_round > 0 ? pv->max_round : 0;
-        int mine = SW_INF;
-        for (int i = threadIdx.x; i < npad; i += blockDim.x)
-            if (visible_len[i] > chain_len[i]) { const int f = B.front[i]; mine = f < mine ? f : mine; }
-        mine = wave_min_i32(mine);
-        if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mine;
-        __syncthreads();
-        r_start = SW_INF;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r_start = s_min[w] < r_start ? s_min[w] : r_start;
-        if (r_start == SW_INF) r_start = last_round;
-        if (r_start < 0) r_start = 0;
-        __syncthreads();   // (everybody has read the old chain lengths and the old state)
-    }
+            int iter_base) {
     // chain lengths visible to this run = the sub-batch's row of the cut table (already on the device)
     for (int i = threadIdx.x; i < npad; i += blockDim.x) { chain_len[i] = visible_len[i]; B.treecnt[i] = 0; }
     if (eval_src)   // the previous run ended on an odd iteration: its exhaustion marks are in half 1, this run reads half 0
@@ -1088,7 +1063,7 @@ k_loop_init(LoopBufs B, int npad, int r_start, int N, int ncap, const int* __res
         t.N = N;
         t.ncap = ncap;
         t.fin_from = fin_from;
-        t.pad_ = B.dbg ? B.st[0].pad_ + B.st[0].iter : 0;   // (diagnostics only: iterations of this context before this loop)
+        t.pad_ = iter_base;   // (diagnostics only: iterations of this context before this loop — the index base of the phase stamps; the host counts them and resets the count on a rewind)
         B.st[0] = t;
     }
     for (int i = threadIdx.x; i < 2 * npad; i += blockDim.x) {
@@ -1534,7 +1509,9 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
         // block's end — one dependent round trip in front of the rows of every group)
         // The `asm` after the row loads pins the first USE of the creator there: the compiler would otherwise wait for it (and
         // for the LDS look-up behind it) before it issues the rows — two dependent round trips per group instead of one.
-        const int kc = kk < mask_from ? mask_from : (kk < mhi ? kk : mhi - 1);
+        int kc = kk < mask_from ? mask_from : (kk < mhi ? kk : mhi - 1);
+        kc = kc < N ? kc : N - 1;   // (an empty band — mhi == mask_from — clamps to mhi: stay inside the events, the value is not used then)
+        kc = kc < 0 ? 0 : kc;
         int crk = cr[kc];
         auto fin_mask = [&]() -> u64 {
             asm volatile("" : "+v"(crk));

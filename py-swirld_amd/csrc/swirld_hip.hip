@@ -206,6 +206,7 @@ struct sw_ctx {
     int64_t stage_calls = 0;
     unsigned long long* d_dbg = nullptr;  // SW_DEBUG_CLOCKS=1: phase stamps of the round-loop kernels
     unsigned long long* d_dbg_blk = nullptr;   // SW_DEBUG_CLOCKS=3: end time of every workgroup of the loop kernels, per iteration
+    int64_t dbg_iter_base = 0;            // round_iterations at the last rewind: the phase stamps are indexed by the iterations since
     int dbg_minor = 1;                    // SW_DEBUG_CLOCKS=2: only the entry / band start / end stamps (the others drain the wave)
     struct { int32_t* p = nullptr; } d_front;   // inside d_rb
     int32_t* d_treecnt = nullptr;                // inside d_rb: tallies evaluated per member in the running loop (k_tally_tree)
@@ -215,7 +216,9 @@ struct sw_ctx {
     std::vector<int32_t> bounds_stage;  // host staging of the cut table (persistent: uploaded without a sync)
     DBuf<int32_t> d_evalround, d_evalpos, d_lo_r, d_cur, d_unres, d_lo_next, d_pos_next, d_farslot, d_force, d_cand, d_gallop;
     DBuf<u64> d_Mb;
-    DBuf<int32_t> d_Pc;    // [MCAP + 1] popcounts of the band masks (row 0 = 0, like d_Mb): the cheap bounds of k_tally_bits<., FILT>
+    DBuf<int32_t> d_Pc;    // [MCAP + 1] popcounts of the band masks (row 0 = 0, like d_Mb): the cheap bounds of k_tally_bits<., FILT>.
+                           // INVARIANT: whoever writes a row of d_Mb writes its popcount here (k_resolve_band's band pass is the only writer of both,
+                           // in its plain and its split form): a `sure` verdict of the filtered tally never looks at the mask itself
     DBuf<int32_t> d_rsc;   // [R][3] round-level agreement of k_elections_tiled: open witnesses, decided flag, arrival ticket
     DBuf<u64> d_found64;   // [2][npad] {event << 32 | slot << 26 | look-ahead} of the members' first passing candidates (LoopBufs::found64)
     // one device block read back with ONE copy per round-loop shot: loop state (x2), sweep error flag, per-member
@@ -225,13 +228,6 @@ struct sw_ctx {
     unsigned char* h_rb_all = nullptr;    // SW_PROV_ROWS pinned slots: the loops of a call's sub-batches are read back one behind the other
     std::vector<hipEvent_t> rb_events, shot_events;   // per slot: read-back complete / last iteration enqueued so far
     int shot_pct = 100, shot_extra = 2;   // SW_SHOT_PCT / SW_SHOT_EXTRA: a loop's first shot = predicted iterations x pct / 100 + extra (tests: 50 makes every loop top up)
-    int bridge = 16;                      // SW_BRIDGE: iterations of the short shot behind a chained start (the rest follows when the previous loop's state was read)
-    int chain = 0;                        // SW_CHAIN: the loop of sub-batch i + 1 is enqueued behind the shot of loop i (k_loop_init, chained start).
-                                          // Off by default (round 5, profiles/r05f_*, r05i_*, r05x_*): with an exact prediction of the iterations
-                                          // it saves ~13 of the ~40 us between two loops (6.05 -> 6.02 ms per pass at 256 members / 1 M events,
-                                          // -1.8 % at 64 members / 100 k events); with a prediction that falls short the chained start refuses,
-                                          // the bridge behind it goes on with the old loop and the host starts the new one again: 6.26-6.34 ms
-                                          // against 6.16-6.19 on the loop-by-loop path (one host round trip)
     size_t rb_bytes = 0;
     RState* d_state = nullptr;
     FameCounters* d_fc = nullptr;   // header of d_newc: the fame counters travel with the new_c flags in one copy
@@ -1135,7 +1131,7 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
     const int np = c->npad, K = c->K;
     hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
                        (int)limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, c->eval_src,
-                       (int)std::min<int64_t>(fin_from, 0x7fffffff), 0, 0);
+                       (int)std::min<int64_t>(fin_from, 0x7fffffff), (int)std::min<int64_t>(c->ctr.round_iterations - c->dbg_iter_base, 0x7fffffff));
     c->eval_src = 0;
     c->ctr.kernel_launches++;
     std::vector<Span> tally_spans, resolve_spans;
@@ -1211,131 +1207,6 @@ int run_round_loop(sw_ctx* c, int r_start, int64_t limit, int64_t n_new_events, 
 }
 
 
-// ---- chained round loops (round 5): the loops of a call's sub-batches enqueued one behind the other --------------------------
-// The host used to sit between two loops: read the state back, find the next start round from the members' front rounds,
-// launch k_loop_init, enqueue the shot (5 gaps of 30-40 us per pass at 256 members / 1 M events).  Now loop i + 1 — k_loop_init
-// in its chained form, which finds the start round on the device and refuses if loop i did not end inside its shot — and its
-// first shot are enqueued while loop i runs; the host reads loop i's state (copied out before the chained start overwrote it)
-// one loop late, for the counters, the finalize launches of sub-batch i and the rare top-up.
-struct LoopRun {
-    int slot = 0;             // read-back slot (= sub-batch index)
-    int64_t limit = 0;        // events visible to the loop
-    int64_t n_new = 0;        // events of its sub-batch
-    int launched = 0;         // iterations enqueued for it
-    int rest = 0;             // a chained start enqueues a short BRIDGE shot only: the rest of the prediction follows once the previous loop's state was read
-    bool chained = false;
-};
-
-// enqueue: start (host-computed start round, or chained), first shot, the copy of the read-back block into the run's slot
-template <int NW>
-int loop_begin(sw_ctx* c, LoopRun& run, int r_start, bool chained, int64_t prev_limit, const int32_t* visible_len, int64_t fin_from) {
-    const int np = c->npad;
-    int shot = predict_shot(c, run.n_new);
-    run.rest = 0;
-    // BRIDGE: a chained start that refuses (the previous loop did not end inside its shot) turns the iterations behind it into more
-    // iterations of the OLD loop — useful ones if they are few, a wasted shot if they are the new loop's whole prediction.  So the
-    // chained start is followed by a short shot only; the host reads the previous loop's state while the bridge runs (~0.25 ms of
-    // slack) and enqueues the rest behind it (loop_rest).
-    if (chained && shot > c->bridge + 8) { run.rest = shot - c->bridge; shot = c->bridge; }
-    if (!chained) CHK(ensure_rounds(c, c->R + shot + 8));   // (a loop started by the host finds the stream idle: the tables may move)
-    hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(std::min(2 * np, 1024)), 0, c->stream, loop_bufs(c), np, r_start,
-                       (int)run.limit, c->NEARCAP, (const int*)visible_len, c->d_chain_len.p, chained ? 0 : c->eval_src,
-                       (int)std::min<int64_t>(fin_from, 0x7fffffff), chained ? 1 : 0, (int)prev_limit);
-    if (!chained) c->eval_src = 0;
-    c->ctr.kernel_launches++;
-    CHK(launch_iterations<NW>(c, shot, nullptr, nullptr));
-    run.launched = shot;
-    run.chained = chained;
-    HIPCHK(c, hipGetLastError());
-    if (run.rest > 0) return SW_OK;   // (event + read-back follow the rest of the shot)
-    HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));
-    // (round 5, measured and dropped — profiles/r05h_knobs_256x1M.log: the copy of the LAST loop's state on a stream of its own,
-    // beside the tail of the call instead of in front of it: the pass went from 6.1 to 13 ms — a copy behind an event of another
-    // stream does not start when that event fires)
-    HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
-    return SW_OK;
-}
-
-// the rest of a chained loop's first shot, behind its bridge (the previous loop was seen to have ended: the chained start took place)
-template <int NW>
-int loop_rest(sw_ctx* c, LoopRun& run) {
-    if (run.rest > 0) {
-        CHK(launch_iterations<NW>(c, run.rest, nullptr, nullptr));
-        run.launched += run.rest;
-        run.rest = 0;
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
-    }
-    return SW_OK;
-}
-
-// wait for the run's state; top up until the loop reports done; the book-keeping of a finished loop.  `next` = the run enqueued
-// (chained) behind this one, if any: when this loop did not end inside its shot, that start refused and its iterations went on
-// with this loop — *next_alive is cleared and the caller starts the next loop again, from the host.
-template <int NW>
-int loop_collect(sw_ctx* c, LoopRun& run, LoopRun* next, bool* next_alive) {
-    const int np = c->npad, K = c->K;
-    RState st{};
-    auto read_slot = [&](int slot) -> int {
-        HIPCHK(c, hipEventSynchronize(c->rb_events[slot]));
-        c->h_rb = c->h_rb_all + (size_t)slot * c->rb_bytes;
-        memcpy(&st, c->h_rb, sizeof st);
-        int ferr = 0;
-        memcpy(&ferr, c->h_rb + 2 * sizeof(RState), sizeof ferr);
-        memcpy(c->front_dev.data(), c->h_rb + 256, np * sizeof(int32_t));
-        if (ferr) return fail(c, SW_EIO, "can_see sweep gave up polling (code %d): internal protocol error", ferr);
-        if (st.err) return fail(c, SW_ERANGE, "round table capacity exceeded (internal)");
-        return SW_OK;
-    };
-    CHK(read_slot(run.slot));
-    if (st.N != (int)run.limit) return fail(c, SW_EIO, "chained round loop: state of another loop in slot %d (N=%d, expected %lld)", run.slot, st.N, (long long)run.limit);
-    if (!st.done && next && *next_alive) {
-        // the chained start behind this loop refused: the iterations enqueued for the next loop (its bridge, or its whole shot) went
-        // on with this one.  Their outcome: a fresh copy of the state (the stream holds nothing else of the next loop yet).
-        run.launched += next->launched;
-        next->rest = 0;
-        *next_alive = false;
-        HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));   // (this loop's last iteration so far lies behind the next run's shot)
-        HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
-        CHK(read_slot(run.slot));
-        if (st.N != (int)run.limit) return fail(c, SW_EIO, "chained round loop: the next loop started although this one had not ended");
-    }
-    while (!st.done) {
-        // rounds <= DAG height + 1, retries <= N / K: anything beyond that is a bug, not work
-        if ((int64_t)run.launched > (int64_t)c->max_height + 2 + c->N / K + 4096)
-            return fail(c, SW_EIO, "round loop did not terminate after %d iterations (r=%d)", run.launched, st.r);
-        const int shot = run.launched < 8 ? 2 : (run.launched < 48 ? 8 : 4);
-        CHK(ensure_rounds(c, c->R + run.launched + shot + 4));   // (the stream is idle here: the tables may move)
-        CHK(launch_iterations<NW>(c, shot, nullptr, nullptr));
-        run.launched += shot;
-        HIPCHK(c, hipEventRecord(c->shot_events[run.slot], c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_rb_all + (size_t)run.slot * c->rb_bytes, c->d_rb, c->rb_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipEventRecord(c->rb_events[run.slot], c->stream));
-        CHK(read_slot(run.slot));
-    }
-    if (run.n_new >= 4096) {  // keep the rate estimate to runs where it means something
-        c->stat_iters += st.iter;
-        c->stat_events += run.n_new;
-    }
-    c->eval_src = st.iter & 1;   // (what a host-started successor is told; a chained one reads it from the state)
-    c->R = st.max_round + 1;
-    if (c->unit_stake && c->tally_impl == 2) {
-        const int32_t* tc = reinterpret_cast<const int32_t*>(c->h_rb + ((unsigned char*)c->d_treecnt - c->d_rb));
-        for (int m = 0; m < np; ++m) c->ctr.tally_evals += tc[m];
-    } else
-        c->ctr.tally_evals += (int64_t)st.evals;
-    c->ctr.far_hops += (int64_t)st.far_hops;
-    c->ctr.round_iterations += st.iter;
-    c->ctr.band_events += (int64_t)st.band_events;
-    return SW_OK;
-}
-
-
-// voter masks (decide_fame part 1) for the witnesses of rounds [r0, R) on `strm`
 template <int NW>
 int launch_voter_masks(sw_ctx* c, int r0, int R, hipStream_t strm) {
     const int np = c->npad;
@@ -1689,65 +1560,6 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         clk.mark(&c->stage_us[4]);
         return SW_OK;
     };
-    // CHAINED loops (round 5; SW_CHAIN=0, profiling, the early finalize and the stage clocks take the loop-by-loop path below):
-    // loop i + 1 is enqueued while loop i runs (loop_begin / loop_collect).  Not chained: a sub-batch that holds a member's first
-    // event (its root row is uploaded by the host in front of the loop).
-    const bool can_chain = c->chain && !c->profiling && !c->debug_timing && c->mid_pct == 0 && S >= 2 && S <= SW_PROV_ROWS;
-    if (can_chain) {
-        std::vector<LoopRun> runs(S);
-        int cap_need = std::max(c->R, 1) + 64;
-        for (int i = 0; i < S; ++i) {
-            runs[i].slot = i;
-            runs[i].limit = cut[i + 1];
-            runs[i].n_new = cut[i + 1] - cut[i];
-            cap_need += predict_shot(c, runs[i].n_new) + 16;
-        }
-        // the round tables must not move while a chained loop is in flight: room for every predicted iteration up front
-        CHK(ensure_rounds(c, cap_need));
-        auto holds_a_root = [&](int i) -> bool {   // (decided from the cut table alone: a member with no event below cut[i] and one below cut[i + 1])
-            for (int m = 0; m < n; ++m)
-                if (bounds_h[(size_t)i * np + m] == 0 && bounds_h[(size_t)(i + 1) * np + m] > 0 && c->front[m] < 0) return true;
-            return false;
-        };
-        auto fits = [&](int i) -> bool {   // the tables hold the iterations enqueued so far plus this loop's shot
-            int need = std::max(c->R, 1) + 8;
-            for (int j = 0; j <= i; ++j) need += (j < i ? runs[j].launched + runs[j].rest : predict_shot(c, runs[j].n_new)) + 4;
-            return need <= c->Rcap;
-        };
-        std::vector<int> rs_host(S, 0);
-        {   // loop 0: from the host
-            bool dirty = false;
-            rs_host[0] = start_round(0, &dirty);
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[0], 0));
-            if (dirty) CHK(upload_row0());
-            clk.mark(&c->stage_us[1]);
-            CHK(loop_begin<NW>(c, runs[0], rs_host[0], false, 0, c->d_bounds.p + (size_t)np, c->fin_band ? cut[0] : 0x7fffffff));
-        }
-        for (int i = 0; i < S; ++i) {
-            bool next_alive = false;
-            if (i + 1 < S && !holds_a_root(i + 1) && fits(i + 1)) {
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i + 1], 0));
-                CHK(loop_begin<NW>(c, runs[i + 1], 0, true, cut[i + 1], c->d_bounds.p + (size_t)(i + 2) * np, c->fin_band ? cut[i + 1] : 0x7fffffff));
-                next_alive = true;
-            }
-            CHK(pending_aux());   // the previous sub-batch's finalize launches, behind the shots just enqueued
-            CHK(loop_collect<NW>(c, runs[i], next_alive ? &runs[i + 1] : nullptr, &next_alive));
-            if (next_alive) CHK(loop_rest<NW>(c, runs[i + 1]));   // (first thing after the state was read: the bridge is running)
-            clk.mark(&c->stage_us[2]);
-            CHK(after_loop(i, rs_host[i], cut[i], c->shot_events[runs[i].slot]));
-            if (i + 1 < S) {
-                bool dirty = false;
-                rs_host[i + 1] = start_round(i + 1, &dirty);   // (what the chained start found on the device; the aux launches of i + 1 need it)
-                if (!next_alive) {
-                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->cs_events[i + 1], 0));
-                    if (dirty) CHK(upload_row0());
-                    CHK(loop_begin<NW>(c, runs[i + 1], rs_host[i + 1], false, 0, c->d_bounds.p + (size_t)(i + 2) * np, c->fin_band ? cut[i + 1] : 0x7fffffff));
-                } else if (dirty) {
-                    return fail(c, SW_EIO, "chained round loop started on a sub-batch that holds a member's first event (internal)");
-                }
-            }
-        }
-    } else
     for (int i = 0; i < S; ++i) {
         const int64_t limit = cut[i + 1];
         bool row0_dirty = false;
@@ -2362,7 +2174,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
 // ====================================================================================
 extern "C" {
 
-int sw_version(void) { return 5; }
+int sw_version(void) { return 6; }
 
 const char* sw_last_error(const sw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -2458,10 +2270,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     knob("SW_BAND_FAST", 0, 1, &c->band_fast);
     if (c->npad > 256) c->tally_filter = 1;
     knob("SW_TALLY_FILTER", 0, 1, &c->tally_filter);
-    knob("SW_CHAIN", 0, 1, &c->chain);
     knob("SW_SPLIT_EMULATE", 0, SW_MAX_PARTS, &c->split_emulate);   // (measurement: the parts of a split played by one context; pin SW_TALLY_IMPL=1 with it)
-    knob("SW_BRIDGE", 2, 512, &c->bridge);
-    c->bridge &= ~1;
     knob("SW_SHOT_PCT", 10, 400, &c->shot_pct);
     knob("SW_SHOT_EXTRA", 0, 64, &c->shot_extra);
     knob("SW_CHUNK_MIN", 64, 1 << 30, &c->chunk_min);
@@ -3617,6 +3426,7 @@ int sw_rewind(sw_ctx* c) {
     c->divided = 0;
     c->R = 0;
     c->sw_dirty_from = 1;
+    c->dbg_iter_base = c->ctr.round_iterations;   // (the phase stamps of the loop kernels count from the rewind)
     c->transactions.clear();
     std::fill(c->ord_pos.begin(), c->ord_pos.end(), 0);
     if (c->exact) CHK(exact_rewind(c));
@@ -3696,7 +3506,6 @@ int sw_split_link(sw_ctx* const* ctxs, int parts) {
         sw_ctx* c = ctxs[q];
         // the split kernels exist for the one-wave-per-slot tally (the default beyond 256 members)
         c->tally_impl = 1; c->tally_auto = false; c->K = c->K_flat; c->K_auto = false;
-        c->chain = 0;
         c->split_part = q;
         c->split_iter = 0;
         c->split_failed = false;

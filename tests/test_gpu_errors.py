@@ -96,7 +96,7 @@ def test_rewind_and_reuse(pkg):
 @pytest.mark.parametrize("name,value", [("SW_TALLY_K", "0"), ("SW_TALLY_K", "abc"), ("SW_CANSEE_IMPL", "5"), ("SW_CANSEE_IMPL", "7"),
                                         ("SW_SKIP", "33"), ("SW_PIPE", "2x"), ("SW_CHUNKS", "9"), ("SW_GRAPH", "2"), ("SW_HALO", "-1"),
                                         ("SW_ELECT_CG", "96"), ("SW_MID_PCT", "100"), ("SW_FIN_BLOCKS", "8"), ("SW_FIN_BAND", "2"), ("SW_GRAPH_BIG", "513"),
-                                        ("SW_BAND_FAST", "2"), ("SW_CHUNK_CFG", "3"), ("SW_TALLY_FILTER", "2"), ("SW_CHAIN", "-1"), ("SW_SHOT_PCT", "5"), ("SW_TALLY_IMPL", "3"), ("SW_BRIDGE", "1")])
+                                        ("SW_BAND_FAST", "2"), ("SW_CHUNK_CFG", "3"), ("SW_TALLY_FILTER", "2"), ("SW_SHOT_PCT", "5"), ("SW_TALLY_IMPL", "3")])
 def test_tuning_knobs_are_validated(pkg, monkeypatch, name, value):
     """the SW_* switches were read with atoi and silently clamped.  A value that is not an
     integer inside the documented range now fails sw_create with SW_EINVAL naming the variable."""

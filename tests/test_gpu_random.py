@@ -40,7 +40,6 @@ def test_random_shapes(pkg, monkeypatch, seed):
     monkeypatch.setenv("SW_BAND_FAST", str(int(np.random.default_rng(8100 + seed).choice([0, 1, 1]))))
     # (round 5) popcount bounds in front of the mask gathers of the one-wave-per-slot tally
     monkeypatch.setenv("SW_TALLY_FILTER", str(int(np.random.default_rng(8200 + seed).choice([0, 1]))))
-    monkeypatch.setenv("SW_CHAIN", str(int(np.random.default_rng(8300 + seed).choice([0, 1, 1]))))
     stake = None
     if n >= 8 and rng.random() < 0.2:  # near-unit weighted stakes (the only weighted kind that progresses)
         stake = np.ones(n, np.uint64)
