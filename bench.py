@@ -83,7 +83,8 @@ def load_traffic(key):
     kernel family from rocprofv3 --pmc passes (FETCH_SIZE doubled + WRITE_SIZE, separate passes) and rocprofv3's own
     average launch durations — measured by profiles/collect_traffic.py, not by this run.  Nothing is quoted for a
     workload the file does not hold, nor from a file measured on other kernel source (`stale`: the file carries the
-    SHA-256 of kernels.hip.h + order.hip.h)."""
+    SHA-256 of kernels.hip.h + order.hip.h).  Returns (bytes per launch, ms per pass by rocprofv3's plain kernel trace of
+    the bench command, commit, command, stale)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(tpath))
@@ -93,7 +94,7 @@ def load_traffic(key):
     w = t.get("workloads", {}).get(key)
     if stale or not w:
         return {}, {}, (w or {}).get("commit"), None, stale
-    return w.get("kernels", {}), w.get("avg_us", {}), w.get("commit"), w.get("workload"), False
+    return w.get("kernels", {}), w.get("ms_per_pass", {}), w.get("commit"), w.get("workload"), False
 
 
 def time_python_reference(ref_path, n, stream, events):
@@ -441,10 +442,11 @@ def main():
              "total_ms": round(total_ms, 3), "alg_bytes_per_launch": int(alg_bytes_total / launches),
              "achieved_GBps": round(ach, 1), "frac": round(ach / PEAK_GBPS, 5),
              "hbm_bytes_per_launch_pmc": traffic.get(name), "served_by": served_by}
-        ru = rocprof_us.get(name)
-        if ru:   # rocprofv3's own duration of this family's launches on this workload (profiles/traffic.json): no event brackets in it
-            d["avg_launch_us_rocprof"] = ru
-            d["total_ms_rocprof"] = round(ru * launches * 1e-3, 3)
+        rp = rocprof_us.get(name)
+        if rp:   # this family's time per pass in rocprofv3's plain kernel trace of this workload (profiles/traffic.json): no event brackets in it
+            ru = rp * 1e3 / launches
+            d["total_ms_rocprof"] = rp
+            d["avg_launch_us_rocprof"] = round(ru, 2)
             d["achieved_GBps_rocprof"] = round(alg_bytes_total / launches / (ru * 1e-6) / 1e9, 1)
             d["frac_rocprof"] = round(d["achieved_GBps_rocprof"] / PEAK_GBPS, 5)
             if traffic.get(name):
@@ -490,13 +492,17 @@ def main():
         if all(traffic.get(k) is not None for k in (cs_name, "k_resolve_band", tally_name)):
             hbm_pmc = int(sum(traffic.get(k, 0) * v for k, v in per_pass.items()))
     path_frac = round(path_gbps / PEAK_GBPS, 5)
+    frac_note = None
+    if path_frac > 1.0:
+        frac_note = ("above 1: SURVEY.md §8d's algorithmic bytes count the tally's n^2 / 8 mask gathers per event, which this path serves from L2 "
+                     "(the band-mask table is a few MB): what crosses the HBM interface is frac_hbm_measured")
     roofline = {
         # the headline fraction is the WHOLE PATH's: algorithmic bytes of one pass / ms_per_step against the HBM
         # peak — `achieved` / `frac`; what the counters saw crossing the HBM interface is `traffic` (bytes per step) /
         # `frac_hbm_measured`.  The kernel named here is the HBM-served family with the largest total time; its own rate is in
         # `dominant_kernel` and in the table.  A family whose bytes are L2 gathers (the tallies) is never quoted against HBM.
         "bound": "hbm", "kernel": dom["kernel"], "achieved": round(path_gbps, 2), "peak": PEAK_GBPS,
-        "unit": "GB/s", "frac": path_frac, "traffic": hbm_pmc,
+        "unit": "GB/s", "frac": path_frac, "frac_note": frac_note, "traffic": hbm_pmc,
         "scope": "whole pass (sw_rewind + sw_divide_rounds + sw_decide_fame): algorithmic bytes per step / ms_per_step; "
                  "traffic = HBM bytes per step by the counters",
         "dominant_kernel": {k: dom.get(k) for k in ("kernel", "launches", "avg_launch_us", "avg_launch_us_rocprof", "alg_bytes_per_launch",
@@ -512,7 +518,7 @@ def main():
         "hbm_bytes_note": "sum over kernel families of (PMC bytes per launch, profiles/traffic.json) x (launches of this run's profiled pass) "
                           "/ ms_per_step: what actually crosses the HBM interface, against algorithmic bytes in frac",
         "avg_launch_us": dom["avg_launch_us"], "launches": dom["launches"],
-        "dominant_by": "largest total time among the HBM-served kernel families (rocprofv3 durations x this run's launches where profiles/traffic.json has this workload)",
+        "dominant_by": "largest time per pass among the HBM-served kernel families (rocprofv3's plain kernel trace of this workload where profiles/traffic.json has it, else this run's event brackets)",
         "kernels": kernels,
         "path_algorithmic_GBps": round(path_gbps, 2), "path_frac": path_frac,
         "path_note": "whole-pass algorithmic bytes (SURVEY.md §8d) / ms_per_step: the path is bound by its dependency "

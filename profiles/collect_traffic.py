@@ -9,8 +9,10 @@ profiles/traffic.json, which bench.py quotes next to the algorithmic bytes.
   Launches that did no work (iterations replayed after the loop finished) are excluded: only
   dispatches above 5 % of the family's maximum count.
   The kernel trace that comes with the FETCH pass also gives every family's average launch duration as rocprofv3
-  sees it (`avg_us`): bench.py ranks the families by that duration x its own launch counts (its hipEvent brackets
-  around plain launches inflate the short loop kernels by 2-3 us each).
+  sees it under the counters (`avg_us`: kernels serialised).  `ms_per_pass` comes from the PLAIN kernel trace of the bench
+  command (kernel_stats.txt of profiles/run_profiles.sh step 1, given with --stats): a family's total time / the passes of
+  that run (= launches of the elections kernel, one per pass) — streams overlapping as in a timed step.  bench.py ranks the
+  families by it (its hipEvent brackets around plain launches inflate the short loop kernels by 2-3 us each).
   The file is keyed by WORKLOAD ("<members>x<events>x<generator mode>"): an existing file is extended, entries
   measured on other kernel source (SHA-256 of kernels.hip.h + order.hip.h) are dropped.
 Usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> <commit> <workload-key> <command> <kernel-substring>..."""
@@ -62,7 +64,30 @@ def avg_duration_us(d, kernel):
     return round(float(live.mean()), 2) if len(live) else round(float(dur.mean()), 2)
 
 
-def main(fd, wd, out, commit, key, workload, kernels):
+def per_pass_from_stats(path, kernels):
+    """{family: ms per pass} from a summarize_rocpd.py table of a bench.py kernel trace"""
+    rows = {}
+    for ln in open(path):
+        parts = ln.rstrip("\n").split()
+        if len(parts) < 9 or not parts[-1].replace(".", "").isdigit():
+            continue
+        name = " ".join(parts[:-8])
+        try:
+            rows[name] = (int(parts[-8]), float(parts[-7]))   # calls, total_us
+        except ValueError:
+            continue
+    passes = sum(c for nme, (c, _t) in rows.items() if "k_elections" in nme)
+    if not passes:
+        return {}
+    out = {}
+    for k in kernels:
+        tot = sum(t for nme, (_c, t) in rows.items() if k in nme)
+        if tot:
+            out[k] = round(tot / passes / 1e3, 4)
+    return out
+
+
+def main(fd, wd, out, commit, key, workload, kernels, stats=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ksha = kernel_source_sha256(root)
     allw = {"kernels_sha256": ksha, "workloads": {},
@@ -76,7 +101,7 @@ def main(fd, wd, out, commit, key, workload, kernels):
             allw["workloads"] = old.get("workloads", {})
     except (OSError, ValueError):
         pass
-    res = {"commit": commit, "workload": workload, "kernels": {}, "avg_us": {}, "detail": {}}
+    res = {"commit": commit, "workload": workload, "kernels": {}, "avg_us": {}, "ms_per_pass": per_pass_from_stats(stats, kernels) if stats else {}, "detail": {}}
     allw["workloads"][key] = res
     for k in kernels:
         f, w = per_kernel(fd, "FETCH_SIZE", k), per_kernel(wd, "WRITE_SIZE", k)
@@ -94,4 +119,10 @@ def main(fd, wd, out, commit, key, workload, kernels):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6], sys.argv[7:])
+    a = sys.argv[1:]
+    st = None
+    if "--stats" in a:
+        i = a.index("--stats")
+        st = a[i + 1]
+        a = a[:i] + a[i + 2:]
+    main(a[0], a[1], a[2], a[3], a[4], a[5], a[6:], st)

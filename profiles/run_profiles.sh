@@ -22,7 +22,7 @@ python profiles/loop_timeline.py "$DB" > $OUT/loop_timeline.txt 2>> $OUT/kt_run.
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python bench.py $PMCARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python bench.py $PMCARGS > $OUT/write.log 2>&1
 TJ=${TRAFFIC_JSON:-$OUT/traffic.json}
-python profiles/collect_traffic.py $OUT/fetch $OUT/write $TJ "$COMMIT" "${TRAFFIC_KEY:-256x1000000x0}" "bench.py $PMCARGS" \
+python profiles/collect_traffic.py --stats $OUT/kernel_stats.txt $OUT/fetch $OUT/write $TJ "$COMMIT" "${TRAFFIC_KEY:-256x1000000x0}" "bench.py $PMCARGS" \
     k_cansee_chunks k_cansee_fixup k_cansee_flow k_cansee_stream k_resolve_band k_tally_bits k_tally_tree k_elections k_voter_masks_bits k_finalize_events k_finalize_check k_finalize_listed \
     k_order_walk k_order_median k_order_sort k_order_bounds > $OUT/traffic.log 2>&1
 # 3. wave / wait / cache counters

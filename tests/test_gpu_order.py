@@ -57,6 +57,41 @@ def test_find_order_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk, bulk, m
     h.close()
 
 
+@pytest.mark.parametrize("env", [
+    {"SW_ORDER_SLAB_MB": "1"},                                  # many groups: the two slabs alternate, every group meets the next one's walk
+    {"SW_ORDER_SLAB_MB": "1", "SW_ORDER_ONE_STREAM": "1"},      # ... on one stream
+    {"SW_ORDER_SLAB_MB": "2", "SW_ORDER_SORT_INLINE": "1"},     # the sorts on the samples' stream
+    {"SW_ORDER_SLAB_MB": "2", "SW_ORDER_LATE_COPY": "1"},       # the caller's copy in one piece at the end
+    {"SW_ORDER_S": "1"}, {"SW_ORDER_S": "37", "SW_ORDER_SLAB_MB": "3"},   # one stretch per chain / more stretches than a chain has events in a group
+])
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1", [(256, 120000, 91, 0, 0, 0), (100, 60000, 92, 2, 0.3, 0.03), (600, 90000, 93, 0, 0, 0)])
+def test_find_order_table_path_under_its_knobs(pkg, n, N, seed, mode, p0, p1, env, monkeypatch):
+    """the group / slab / stream structure of the bulk path changes nothing: every variant equals the search form's
+    order (which the tests above pin to the oracle), and for the first shape the oracle itself"""
+    cr, sp, op, t, sig = pkg.synth_hashgraph(n, N, seed, mode, p0, p1)
+    t = t + (np.arange(N) % 5) * 0.5
+    def order(envs):
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        h = pkg.Hashgraph(n)
+        h.append_events(cr, sp, op, t, sig)
+        h.divide_rounds(0, N)
+        tx = np.array(h.find_order(h.decide_fame()))
+        h.close()
+        for k in envs:
+            monkeypatch.delenv(k)
+        return tx
+    ref = order({"SW_ORDER_BULK": "0"}) if n <= 512 else order({})
+    got = order(dict(env, SW_ORDER_BULK="1"))
+    assert len(ref) > 20000 and np.array_equal(got, ref)
+    if n == 100:
+        from oracle.oracle import Oracle
+        o = Oracle(n)
+        o.append_events(cr, sp, op, t, sig)
+        o.divide_rounds(0, N)
+        assert np.array_equal(ref, o.find_order(o.decide_fame()))
+
+
 def test_host_sort_fallback_matches(pkg, monkeypatch):
     """The per-round device sort falls back to a host sort for oversize rounds and for
     (timestamp, 8-byte key) ties; force that path and compare."""
