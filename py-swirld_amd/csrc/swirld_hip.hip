@@ -2259,6 +2259,11 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     knob("SW_MID_PCT", 0, 99, &c->mid_pct);
     knob("SW_FIN_BAND", 0, 1, &c->fin_band);
     knob("SW_FIN_BLOCKS", 64, 8192, &c->fin_blocks);
+    // beyond 512 members the sweep is the level-bucketed kernel (1024-thread workgroups, one per CU) and the loop kernels are
+    // throughput-bound: side by side they cost each other more than the overlap hides (round 6, profiles/r06_pipe_1024.txt: 1024
+    // members / 2 M events 32.55 -> 31.49 ms, 8 M events 125.4 -> 124.0, coin-round stress 44.5 -> 38.9; at 512 members the opposite,
+    // 20.7 -> 26.3): every sweep of a call first, then ONE loop
+    if (c->npad > 512) c->pipe = 1;
     knob("SW_PIPE", 1, SW_PROV_ROWS - 1, &c->pipe);   // (head + pipe sub-batches: every one of them has a row of chunk counters)
     if (c->npad > 256) c->cansee_impl = 3;  // wide member counts: the level-bucketed streaming kernel is faster than the dataflow sweep there
     knob("SW_CANSEE_IMPL", 2, 6, &c->cansee_impl);
