@@ -1968,12 +1968,12 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
         const bool bulk = NW > 8 || (bulk_min > 0 && n_acc >= bulk_min);
         hipStream_t tail = c->stream;   // the stream the last kernels of the call are on
         if (bulk) {
-            // The table is built for GROUPS of consecutive round entries whose events fit SW_ORDER_SLAB_MB [128 per 256 columns]
+            // The table is built for GROUPS of consecutive round entries whose events fit SW_ORDER_SLAB_MB [256 per 256 columns: 4 groups per 1 M events — 128 and 512 are both 0.15-0.3 ms slower, profiles/r06_measured_and_dropped.txt]
             // of table — a slab that stays allocated instead of one table as large as the can_see rows of everything the call
             // orders — and there are TWO slabs: the samples, the sort and the read-back of group g run on a second stream
             // beside the walk of group g + 1 (the walk is bound by its stores, the samples by their selection loops).
             constexpr int P = order_tile(NW);
-            const int64_t slab_mb = getenv("SW_ORDER_SLAB_MB") ? atoll(getenv("SW_ORDER_SLAB_MB")) : 128 * std::max(1, NW / 4);
+            const int64_t slab_mb = getenv("SW_ORDER_SLAB_MB") ? atoll(getenv("SW_ORDER_SLAB_MB")) : 256 * std::max(1, NW / 4);
             const int64_t pad = (int64_t)P * np;   // every chain rounds its positions up to whole tiles
             const int64_t slab_pos = std::max<int64_t>(2 * pad, (slab_mb << 20) / ((int64_t)n * 4));
             struct Group { int i0, i1; };
