@@ -161,6 +161,8 @@ int sw_get_range_stats(sw_ctx* ctx, int64_t* provisional, int64_t* repaired, int
  *   afterwards       EVERY part calls sw_divide_rounds with the same arguments, each from its own host thread (the calls meet
  *                    iteration by iteration; a part that never arrives makes the others fail with SW_EIO after 30 s);
  *                    sw_decide_fame / sw_find_order / getters per context as usual — each part ends with the complete state.
+ *   sw_rewind        of linked contexts: EVERY part rewinds and is synchronised (sw_synchronize) before ANY part divides again — a
+ *                    part's first band kernel stores into the others' tables, which their rewind would wipe afterwards.
  *   sw_split_unlink  dissolves the group (also done by sw_destroy of any of its contexts).
  * Results are those of an unlinked context (tests/test_gpu_split_loop.py: parts on one GPU against the oracle).
  */

@@ -119,6 +119,15 @@ class Hashgraph:
         self._chk(self._L.sw_split_unlink(self._h))
 
     @staticmethod
+    def split_rewind(parts):
+        """rewind every linked part and wait for all of them: none may divide again before every one has rewound
+        (include/swirld_hip.h, part 3)"""
+        for p in parts:
+            p.rewind()
+        for p in parts:
+            p.synchronize()
+
+    @staticmethod
     def split_divide_rounds(parts, first, K):
         """divide_rounds(first, K) on every linked context at once, one host thread per part (the C calls release the GIL and meet
         iteration by iteration on the device); raises the first part's error."""

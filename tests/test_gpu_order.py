@@ -64,7 +64,8 @@ def test_find_order_matches_oracle(pkg, n, N, seed, mode, p0, p1, chunk, bulk, m
     {"SW_ORDER_SLAB_MB": "2", "SW_ORDER_LATE_COPY": "1"},       # the caller's copy in one piece at the end
     {"SW_ORDER_S": "1"}, {"SW_ORDER_S": "37", "SW_ORDER_SLAB_MB": "3"},   # one stretch per chain / more stretches than a chain has events in a group
 ])
-@pytest.mark.parametrize("n,N,seed,mode,p0,p1", [(256, 120000, 91, 0, 0, 0), (100, 60000, 92, 2, 0.3, 0.03), (600, 90000, 93, 0, 0, 0)])
+@pytest.mark.parametrize("n,N,seed,mode,p0,p1", [(256, 120000, 91, 0, 0, 0), (100, 60000, 92, 2, 0.3, 0.03), (600, 90000, 93, 0, 0, 0),
+                                                  (256, 200000, 94, 1, 0.5, 0.01)])   # (two cliques: rounds of more than 4096 events — the global-memory sort behind the groups)
 def test_find_order_table_path_under_its_knobs(pkg, n, N, seed, mode, p0, p1, env, monkeypatch):
     """the group / slab / stream structure of the bulk path changes nothing: every variant equals the search form's
     order (which the tests above pin to the oracle), and for the first shape the oracle itself"""

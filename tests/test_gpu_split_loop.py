@@ -92,6 +92,26 @@ def test_split_round_loop_1024_members(pkg, oracle_pool, parts):
         h.close()
 
 
+def test_split_rewind_and_divide_again(pkg):
+    """linked contexts rewound together divide again to the same state (the measured step of bench.py --split strong)"""
+    from oracle.oracle import Oracle
+    n, N = 96, 30000
+    stream = pkg.synth_hashgraph(n, N, 41, 2, 0.3, 0.05)
+    o = Oracle(n)
+    o.append_events(*stream)
+    o.divide_rounds(0, N)
+    onc = [int(r) for r in o.decide_fame()]
+    hs, ncs = run_split(pkg, n, stream, 3)
+    for _ in range(2):
+        pkg.Hashgraph.split_rewind(hs)
+        pkg.Hashgraph.split_divide_rounds(hs, 0, N)
+        for h in hs:
+            assert [int(r) for r in h.decide_fame()] == onc
+    for h in hs:
+        compare_state(h, o, N, can_see_step=15_000)
+        h.close()
+
+
 def test_split_link_refuses_what_it_cannot_do(pkg):
     a, b = pkg.Hashgraph(16), pkg.Hashgraph(16)
     st = pkg.synth_hashgraph(16, 2000, 5)
