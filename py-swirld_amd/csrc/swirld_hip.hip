@@ -95,6 +95,7 @@ struct sw_ctx {
     int split_part = 0;
     long long split_iter = 0;      // iterations of the round loop enqueued since the link
     bool split_failed = false;     // a meeting of the parts failed (a part gave up): the call reports it
+    int split_saved[4] = {0, 0, 0, 0};   // tally choice of the context before the link pinned the one-wave-per-slot tally (restored by the unlink)
     int split_emulate = 0;         // SW_SPLIT_EMULATE (measurement): this many parts played by this one context, one behind the other
     VmTable vm;
     int64_t first_resident = 0;   // can_see rows below this event index have been evicted (windowed mode)
@@ -3464,7 +3465,12 @@ int sw_reset(sw_ctx* c) {
 static void split_dissolve(SplitGroup* g) {
     if (!g) return;
     for (int q = 0; q < g->parts; ++q)
-        if (g->ctx[q]) { (void)hipStreamSynchronize(g->ctx[q]->stream); g->ctx[q]->split = nullptr; }
+        if (g->ctx[q]) {
+            sw_ctx* c = g->ctx[q];
+            (void)hipStreamSynchronize(c->stream);
+            if (c->split == g) { c->tally_impl = c->split_saved[0]; c->tally_auto = c->split_saved[1] != 0; c->K = c->split_saved[2]; c->K_auto = c->split_saved[3] != 0; }   // (what the link pinned)
+            c->split = nullptr;
+        }
     for (int w = 0; w < 2; ++w)
         for (int q = 0; q < SW_MAX_PARTS; ++q)
             for (auto e : g->ev[w][q]) if (e) (void)hipEventDestroy(e);
@@ -3510,6 +3516,7 @@ int sw_split_link(sw_ctx* const* ctxs, int parts) {
     for (int q = 0; q < parts; ++q) {
         sw_ctx* c = ctxs[q];
         // the split kernels exist for the one-wave-per-slot tally (the default beyond 256 members)
+        c->split_saved[0] = c->tally_impl; c->split_saved[1] = c->tally_auto; c->split_saved[2] = c->K; c->split_saved[3] = c->K_auto;
         c->tally_impl = 1; c->tally_auto = false; c->K = c->K_flat; c->K_auto = false;
         c->split_part = q;
         c->split_iter = 0;
