@@ -40,6 +40,16 @@ def test_random_shapes(pkg, monkeypatch, seed):
     monkeypatch.setenv("SW_BAND_FAST", str(int(np.random.default_rng(8100 + seed).choice([0, 1, 1]))))
     # (round 5) popcount bounds in front of the mask gathers of the one-wave-per-slot tally
     monkeypatch.setenv("SW_TALLY_FILTER", str(int(np.random.default_rng(8200 + seed).choice([0, 1]))))
+    # (round 6) find_order through the first-descendant table whatever the size of the call, under its group / stream knobs
+    org = np.random.default_rng(8400 + seed)
+    if org.random() < 0.6:
+        monkeypatch.setenv("SW_ORDER_BULK", "1")
+        if org.random() < 0.5:
+            monkeypatch.setenv("SW_ORDER_SLAB_MB", str(int(org.choice([1, 1, 2, 8]))))
+        if org.random() < 0.3:
+            monkeypatch.setenv("SW_ORDER_S", str(int(org.choice([1, 3, 64]))))
+        if org.random() < 0.25:
+            monkeypatch.setenv(str(org.choice(["SW_ORDER_ONE_STREAM", "SW_ORDER_SORT_INLINE", "SW_ORDER_LATE_COPY"])), "1")
     stake = None
     if n >= 8 and rng.random() < 0.2:  # near-unit weighted stakes (the only weighted kind that progresses)
         stake = np.ones(n, np.uint64)
