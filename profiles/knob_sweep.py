@@ -13,7 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("py-swirld_amd")
 if os.environ.get("SWEEP_LIB"):   # A/B of two builds on one box: another libswirld_hip.so for this process (the loader reads the path at its first call)
-    importlib.import_module("py-swirld_amd._lib").LIB_PATH = os.path.abspath(os.environ["SWEEP_LIB"])
+    _l = importlib.import_module("py-swirld_amd._lib")
+    _l.LIB_PATH = os.path.abspath(os.environ["SWEEP_LIB"])
+    import ctypes as _C
+    _have = _C.CDLL(_l.LIB_PATH)
+    for _name in [k for k in _l.SIGNATURES if not hasattr(_have, k)]:   # (an older build: entries it does not export are not bound)
+        del _l.SIGNATURES[_name]
     print("library:", os.environ["SWEEP_LIB"], flush=True)
 
 args = sys.argv[1:]

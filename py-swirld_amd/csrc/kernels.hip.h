@@ -1086,8 +1086,11 @@ k_resolve_band(LoopBufs B, int par, int npad, int K, int gallop_after, int skip,
                const int* __restrict__ chain_start, const int* __restrict__ chain_len,
                const int* __restrict__ chain_ev, int* lo, int* lopos,
                const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ op, u64* Mb,
-               int* __restrict__ round_out, u64* __restrict__ S_out, int* __restrict__ Pc, SplitDst sd) {
+               int* __restrict__ round_out, u64* __restrict__ S_out, int* __restrict__ Pc, const SplitDst* __restrict__ sdp) {
     static_assert(!(FAST && SPLIT), "the split form takes the generic band path");
+    // (the parts' tables come through a POINTER: by value they were 400 bytes of kernel arguments on every launch of the plain
+    // loop too, and the host, which enqueues an iteration about as fast as the device runs it, got 1.5 % slower)
+    const SplitDst& sd = *(SPLIT ? sdp : reinterpret_cast<const SplitDst*>(B.st));
     __shared__ int s_red[2][4][16];  // [parity][quantity][wave]: per-wave partial results
     __shared__ int s_thr[1024];
     __shared__ int s_ln[1024];    // lo[r+1][b] when member b is resolved for this round
@@ -1958,7 +1961,8 @@ k_tally_bits(LoopBufs B, int par, int K, int skip, int mb_prefetch,
              const int* __restrict__ chain_start, const int* __restrict__ chain_len,
              const int* __restrict__ chain_ev,
              const int* __restrict__ L, const int* __restrict__ cr, const int* __restrict__ sp,
-             const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad, const int* __restrict__ Pc, SplitDst sd) {
+             const int* __restrict__ op, const uint32_t* __restrict__ Mb32, uint32_t tot2, int npad, const int* __restrict__ Pc, const SplitDst* __restrict__ sdp) {
+    const SplitDst& sd = *(SPLIT ? sdp : reinterpret_cast<const SplitDst*>(B.st));   // (only the split form looks at it)
     constexpr int W32 = 2 * NW;          // 32-bit words per mask
     constexpr int G = 64 / W32;          // hop groups
     constexpr int PLT = ilog2_c(64 * NW) + 1;  // planes for counts up to npad

@@ -95,6 +95,8 @@ struct sw_ctx {
     int split_part = 0;
     long long split_iter = 0;      // iterations of the round loop enqueued since the link
     bool split_failed = false;     // a meeting of the parts failed (a part gave up): the call reports it
+    SplitDst* d_split = nullptr;   // device copies of the SplitDst the split kernels read: [0] this part's (linked), [q] part q's (SW_SPLIT_EMULATE)
+    SplitDst split_up[SW_MAX_PARTS] = {};   // ... and what was uploaded last
     int split_saved[4] = {0, 0, 0, 0};   // tally choice of the context before the link pinned the one-wave-per-slot tally (restored by the unlink)
     int split_emulate = 0;         // SW_SPLIT_EMULATE (measurement): this many parts played by this one context, one behind the other
     VmTable vm;
@@ -899,6 +901,19 @@ SplitDst split_dst(const sw_ctx* c) {
     return d;
 }
 
+// the device copy of a SplitDst (slot 0: the linked part's; slot q: part q of an emulated split), uploaded when it changed
+const SplitDst* split_dev(sw_ctx* c, int slot, const SplitDst& d) {
+    if (!c->d_split) {
+        if (hipMalloc((void**)&c->d_split, sizeof(SplitDst) * SW_MAX_PARTS) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        memset((void*)c->split_up, 0xff, sizeof c->split_up);
+    }
+    if (memcmp(&c->split_up[slot], &d, sizeof d) != 0) {
+        c->split_up[slot] = d;
+        if (hipMemcpyAsync(c->d_split + slot, &c->split_up[slot], sizeof d, hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+    }
+    return c->d_split + slot;
+}
+
 // One boundary of a split iteration: this part's kernel of the boundary is enqueued — record its event, tell the others, and
 // make this part's stream wait for theirs (each waited for only once its owner has recorded it).  false: a part gave up.
 bool split_meet(sw_ctx* c, int which, long long it) {
@@ -930,11 +945,13 @@ void enqueue_iteration_split(sw_ctx* c, int par) {
     const uint32_t tot2 = 2u * c->tot;
     const LoopBufs B = loop_bufs(c);
     const SplitDst sd = split_dst(c);
+    const SplitDst* sdp = split_dev(c, 0, sd);
+    if (!sdp) { c->split->abort.store(1); c->split_failed = true; return; }
     const long long it = c->split_iter++;
     hipLaunchKernelGGL((k_resolve_band<NW, false, true>), dim3(c->band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                        c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                        (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, sd);
+                       (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, sdp);
     if (!split_meet(c, 0, it)) { c->split_failed = true; return; }
     const int members_here = (np - sd.part + sd.parts - 1) / sd.parts;
     const int tally_blocks = (members_here * K + 3) / 4;
@@ -942,7 +959,7 @@ void enqueue_iteration_split(sw_ctx* c, int par) {
         hipLaunchKernelGGL(kern, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, 0,
                            (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                            (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                           (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sd);
+                           (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sdp);
     };
     if (c->tally_filter) tally_bits(k_tally_bits<NW, true, true>);
     else tally_bits(k_tally_bits<NW, false, true>);
@@ -964,27 +981,27 @@ void enqueue_iteration_emulated(sw_ctx* c, int par, int parts) {
     sd.parts = parts; sd.ndst = 1;
     sd.Mb[0] = c->d_Mb.p + NW; sd.Pc[0] = c->d_Pc.p + 1; sd.S[0] = c->d_S.p; sd.round[0] = c->d_round.p;
     sd.found64[0] = c->d_found64.p; sd.farslot[0] = c->d_farslot.p;
+    const SplitDst* sdq[SW_MAX_PARTS];
+    for (int q = 0; q < parts; ++q) { sd.part = q; sdq[q] = split_dev(c, q, sd); if (!sdq[q]) { c->split_failed = true; return; } }
     for (int q = 0; q < parts; ++q) {
-        sd.part = q;
         hipLaunchKernelGGL((k_resolve_band<NW, false, true>), dim3(c->band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                            c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                            (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, sd);
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, sdq[q]);
     }
     for (int q = 0; q < parts; ++q) {
-        sd.part = q;
         const int members_here = (np - q + parts - 1) / parts;
         const int tally_blocks = (members_here * K + 3) / 4;
         if (c->tally_filter)
             hipLaunchKernelGGL((k_tally_bits<NW, true, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, 0,
                                (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                                (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sd);
+                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sdq[q]);
         else
             hipLaunchKernelGGL((k_tally_bits<NW, false, true>), dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, 0,
                                (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                                (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sd);
+                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, sdq[q]);
     }
     c->ctr.kernel_launches += 2 * parts;
 }
@@ -1005,7 +1022,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
         hipLaunchKernelGGL(kern, dim3(band_blocks), dim3(bt), 0, c->stream, B, par, np, K, c->gallop_after, c->skip,
                            c->NEARCAP, c->MCAP, c->Rcap, (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p,
                            (const int*)c->d_chain_ev.p, c->d_lo.p, c->d_lopos.p,
-                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, SplitDst{});
+                           (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_op.p, c->d_Mb.p + NW, c->d_round.p, c->d_S.p, c->d_Pc.p + 1, (const SplitDst*)nullptr);
     };
     if constexpr (NW <= 4) {
         if (c->band_fast) resolve_band(k_resolve_band<NW, true>);
@@ -1022,7 +1039,7 @@ void enqueue_iteration(sw_ctx* c, int par, std::vector<Span>* tally_spans, std::
             hipLaunchKernelGGL(kern, dim3(tally_blocks), dim3(256), 0, c->stream, B, par, K, c->skip, c->tally_pf,
                                (const int*)c->d_chain_start.p, (const int*)c->d_chain_len.p, (const int*)c->d_chain_ev.p,
                                (const int*)c->d_L.p, (const int*)c->d_cr.p, (const int*)c->d_sp.p, (const int*)c->d_op.p,
-                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, SplitDst{});
+                               (const uint32_t*)c->d_Mb.p, tot2, np, (const int*)c->d_Pc.p, (const SplitDst*)nullptr);
         };
         if (c->tally_filter) tally_bits(k_tally_bits<NW, true>);
         else tally_bits(k_tally_bits<NW, false>);
@@ -2463,6 +2480,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_ord_rounds); dfree(c->d_fwm); dfree(c->d_ordat); dfree(c->d_rowsum); dfree(c->d_grp); dfree(c->d_oblk);
     if (c->h_ord) (void)hipHostFree(c->h_ord);
     if (c->h_ord_stage) (void)hipHostFree(c->h_ord_stage);
+    if (c->d_split) (void)hipFree(c->d_split);
     c->transactions.release();
     if (c->stream_ord) (void)hipStreamDestroy(c->stream_ord);
     for (auto st : c->stream_srt) if (st) (void)hipStreamDestroy(st);
