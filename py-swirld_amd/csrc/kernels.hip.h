@@ -168,133 +168,36 @@ __device__ __forceinline__ void lds_barrier() {
 
 
 
-// Level-bucketed can_see sweep (round 1; serves more than 256 members): per member an LDS ring of the H most
-// recent row slices (slot = chain position mod H) + the level descriptors streamed
-// through an LDS staging ring a chunk ahead (no global-memory latency on the per-level
-// critical path) + no per-level drain of the global stores: a workgroup-wide drain + barrier
-// is taken only in the (rare) levels where some parent row is not in the ring and has to be
-// re-read from memory.  A level holds at most one event per member (equal heights imply
-// different creators), so MAXP * (1024 / CB) >= npad covers any level in one pass.
-template <int CB, int MAXP, int BT>
-__global__ void __launch_bounds__(BT)
-k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-                int* L, int npad, int H, int chs) {
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    constexpr int NS = 4;
-    const int CH = 1 << chs;  // descriptors per staging chunk (power of two, npad <= CH <= BT)
-    int4* dstage = (int4*)smem;                              // [NS][CH]
-    int* ring = smem + (size_t)NS * CH * 4;                  // [npad][H][CB]
-    int* ring_ev = ring + (size_t)npad * H * CB;             // [npad][H]
-    int* s_miss = ring_ev + (size_t)npad * H;                // [2]
-    const int tid = threadIdx.x;
-    const int col = tid % CB;
-    const int sub = tid / CB;
-    // XCD-aware column groups: workgroup b runs on XCD b % 8 (observed); give each XCD a
-    // contiguous run of column groups so that its L2 assembles whole 128-byte lines of a row
-    const int nblk = gridDim.x;
-    const int grp = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
-    const int gcol = grp * CB + col;
-    constexpr int EPB = BT / CB;
-    const int hm = H - 1;
-    const int total = lev_start[nlev];
-    for (int i = tid; i < npad * H; i += BT) ring_ev[i] = -1;
-    if (tid < 2) s_miss[tid] = 0;
-    // descriptor chunks 0 and 1 resident, chunk 2 in flight in registers
-    for (int q = 0; q < 2; ++q)
-        for (int i = tid; i < CH; i += BT) {
-            const int gi = q * CH + i;
-            dstage[(size_t)q * CH + i] = gi < total ? desc[gi] : make_int4(-1, -1, -1, 0);
-        }
-    int pend_q = 2;
-    int4 pend = make_int4(-1, -1, -1, 0);
-    if (tid < CH && pend_q * CH + tid < total) pend = desc[(size_t)pend_q * CH + tid];
-    lds_barrier();
-    int s_cur = lev_start[0];
-    int t_cur = lev_start[1];
-    int t_nxt = nlev > 1 ? lev_start[2] : t_cur;
-    int4 dcur[MAXP];
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-        const int i = s_cur + p * EPB + sub;
-        dcur[p] = i < t_cur ? dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))] : make_int4(-1, -1, -1, 0);
-    }
-    for (int lv = 0; lv < nlev; ++lv) {
-        const int t_nn = lv + 2 < nlev ? lev_start[lv + 3] : t_nxt;
-        const int n_cur = t_cur - s_cur;   // events in this level (uniform)
-        const int n_nxt = t_nxt - t_cur;   // events in the next level
-        // make the chunks the NEXT level needs resident (written before barrier 1 below)
-        const int need_q = t_nxt > 0 ? (t_nxt - 1) >> chs : 0;
-        while (need_q >= pend_q) {
-            if (tid < CH) dstage[(size_t)(pend_q % NS) * CH + tid] = pend;
-            ++pend_q;
-            pend = make_int4(-1, -1, -1, 0);
-            if (tid < CH && (size_t)pend_q * CH + tid < (size_t)total) pend = desc[(size_t)pend_q * CH + tid];
-        }
-        if (tid == 0) s_miss[(lv + 1) & 1] = 0;
-        int a[MAXP], b[MAXP];
-        unsigned miss = 0;
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) {  // read phase: parents from the ring
-            a[p] = -1;
-            b[p] = -1;
-            if (p * EPB < n_cur) {  // uniform: skip passes this level does not need
-                const int4 d = dcur[p];
-                if (d.x >= 0 && d.y >= 0) {
-                    const int ce = d.w & 1023;
-                    const int co = (d.w >> 10) & 1023;
-                    const int ss = (((d.w >> 20) & 63) - 1) & hm;
-                    const int so = ((d.w >> 26) & 63) & hm;
-                    if (ring_ev[ce * H + ss] == d.y) a[p] = ring[(ce * H + ss) * CB + col];
-                    else miss |= 1u << (2 * p);
-                    if (ring_ev[co * H + so] == d.z) b[p] = ring[(co * H + so) * CB + col];
-                    else miss |= 2u << (2 * p);
-                }
-            }
-        }
-        if (miss) s_miss[lv & 1] = 1;
-        lds_barrier();  // every ring read of this level is done
-        if (s_miss[lv & 1]) {  // rare, workgroup-uniform: re-read rows from memory
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores ...
-            lds_barrier();                                     // ... before anyone re-reads
-#pragma unroll
-            for (int p = 0; p < MAXP; ++p) {
-                const int4 d = dcur[p];
-                if (miss & (1u << (2 * p)))
-                    a[p] = __hip_atomic_load(&L[(size_t)d.y * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (miss & (2u << (2 * p)))
-                    b[p] = __hip_atomic_load(&L[(size_t)d.z * npad + gcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        int4 dn[MAXP];
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) {  // write phase
-            if (p * EPB < n_cur) {
-                const int4 d = dcur[p];
-                if (d.x >= 0) {
-                    const int ce = d.w & 1023;
-                    const int se = ((d.w >> 20) & 63) & hm;
-                    int v = a[p] > b[p] ? a[p] : b[p];
-                    if (gcol == ce) v = d.x;
-                    L[(size_t)d.x * npad + gcol] = v;
-                    ring[(ce * H + se) * CB + col] = v;
-                    if (col == 0) ring_ev[ce * H + se] = d.x;
-                }
-            }
-            dn[p] = make_int4(-1, -1, -1, 0);
-            if (p * EPB < n_nxt) {  // descriptors of the next level
-                const int i = t_cur + p * EPB + sub;
-                if (i < t_nxt) dn[p] = dstage[(size_t)((i >> chs) % NS) * CH + (i & (CH - 1))];
-            }
-        }
-        lds_barrier();
-        s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn;
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) dcur[p] = dn[p];
-    }
+// A load the compiler's wait-count pass does not see: issued and waited for inside one asm
+// statement.  A visible load inside the worker loop would make the pass put `s_waitcnt vmcnt(0)`
+// in front of every later use of the (reused) destination register, i.e. drain the wave's stores
+// on every trip.  sc1: served by L2, bypassing this CU's vector L1.
+__device__ __forceinline__ int load_sc1_and_wait(const int* ptr) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ptr) : "memory");
+    return v;
 }
 
+// helpers of the level-bucketed sweep (k_cansee_stream, below the column vectors)
+__device__ __forceinline__ void wait_vm_at_most(int n) {   // n = a LOWER bound of the VMEM instructions issued behind the one waited for
+    if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
-
+// one wave's 1 KB piece of a staging chunk: lane i's 16 bytes land at lds_dst + 16 i (lds_dst wave-uniform, in an SGPR)
+__device__ __forceinline__ void lds_dma_16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 
 // ---------------------------------------------------------------------------------
@@ -325,16 +228,6 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
 //    MPL chains + 64 loader lanes; 1024 members run as 512 lanes x 2 chains.
 // ---------------------------------------------------------------------------------
 #define SW_CBAR() asm volatile("" ::: "memory")
-
-// A load the compiler's wait-count pass does not see: issued and waited for inside one asm
-// statement.  A visible load inside the worker loop would make the pass put `s_waitcnt vmcnt(0)`
-// in front of every later use of the (reused) destination register, i.e. drain the wave's stores
-// on every trip.  sc1: served by L2, bypassing this CU's vector L1.
-__device__ __forceinline__ int load_sc1_and_wait(const int* ptr) {
-    int v;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ptr) : "memory");
-    return v;
-}
 
 template <int NW, int MPL, int F, int H, bool WIDE, bool DBG>
 __global__ void __launch_bounds__(64 * NW / MPL + 64)
@@ -587,6 +480,150 @@ __device__ __forceinline__ void store_cols(int* ptr, const int (&v)[C]) {
     if constexpr (C == 4) *reinterpret_cast<int4*>(ptr) = make_int4(v[0], v[1], v[2], v[3]);
     else *reinterpret_cast<int2*>(ptr) = make_int2(v[0], v[1]);
 }
+
+// ---------------------------------------------------------------------------------
+// Level-bucketed can_see sweep (serves more than 256 members; tests/model: the oracle's own loop, level by level).
+// One workgroup = CB adjacent columns of every row, one THREAD per event of a DAG level (a level holds at most
+// one event per member: equal heights imply different creators), the CB values of a row slice as one vector:
+// one ring read per parent, one 4·CB-byte store per event.  Per member an LDS ring of the H most recent row
+// slices (slot = chain position mod H, tag = event id); the level descriptors stream through an LDS staging
+// ring (NS chunks of CH >= npad descriptors: a level spans at most two chunks).
+//
+// Round 6 rewrite (the kernel is exposed beyond 512 members since the sweep no longer hides behind the round
+// loop there; profiles/r06_final_1024_pmc_summary.txt on the previous form — one thread per (event, column),
+// 4 passes of 256 events): 136 VALU instructions per wave and level on 16 waves = 0.9 us of pure issue per level,
+// and `s_waitcnt vmcnt(0)` in front of every store (the compiler cannot tell whether a parent value came from the
+// miss path's global load, and a descriptor chunk prefetched into registers is waited for through the same in-order
+// counter as the stores): 1.9 us per level, 10.4 ms per 2 M events at 1024 members.  Now
+//   * descriptor decode, tag compares and addresses are paid once per event, not once per (event, column); waves
+//     whose slice of the level is empty skip the level through scalar branches;
+//   * no drain of the global stores on the per-level path: the staging chunks arrive by LDS-DMA
+//     (`global_load_lds_dwordx4`, 1 KB pieces, no registers, invisible to the compiler's wait-count pass); a wave
+//     counts the store instructions it has certainly issued since its last piece and waits, when the chunk is first
+//     needed, for `vmcnt(that count)` — loads and stores retire in order, so normally it does not wait at all; the
+//     miss path (a parent row no longer in the ring: workgroup-wide drain + barrier, then re-read from L2) loads
+//     inside asm statements that wait for themselves;
+//   * tag and value of both parents are requested together, the next level's descriptor and the miss flag together
+//     behind the barrier: two LDS round trips and two LDS-only barriers per level.
+// ---------------------------------------------------------------------------------
+template <int CB>
+__global__ void __launch_bounds__(1024)
+k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
+                int* L, int npad, int H, int chs) {
+    typedef typename ColVec<CB>::T V;
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr int NS = 4;
+    const int CH = 1 << chs;  // descriptors per staging chunk (power of two, >= npad = blockDim.x)
+    const int smask = NS * CH - 1;
+    int4* dstage = (int4*)smem;                              // [NS * CH], descriptor i at i & smask
+    V* vals = (V*)(dstage + (size_t)NS * CH);                // [npad][H]
+    int* tags = (int*)(vals + (size_t)npad * H);             // [npad][H]
+    int* s_miss = tags + (size_t)npad * H;                   // [2]
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);   // first event slot of this wave
+    // XCD-aware column groups: workgroup b runs on XCD b % 8 (observed); give each XCD a
+    // contiguous run of column groups so that its L2 assembles whole 128-byte lines of a row
+    const int nblk = gridDim.x;
+    const int grp = (nblk % 8 == 0) ? (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int gcol0 = grp * CB;
+    char* const Lcol = reinterpret_cast<char*>(L + gcol0);
+    const unsigned rowb = (unsigned)npad * 4u;
+    const int hm = H - 1;
+    const int total = lev_start[nlev];
+    const int last_desc = total > 0 ? total - 1 : 0;
+    const unsigned stage_lds = (unsigned)(size_t)dstage;     // (the low half of a generic LDS address is the LDS byte address)
+    // this wave's pieces of chunk q -> slot q % NS (entries beyond the last descriptor hold a copy of it: never read)
+    auto issue_chunk = [&](int q) {
+        for (int base = wave0; base < CH; base += BT) {
+            const long long gi = (long long)q * CH + base + (tid & 63);
+            const unsigned dst = stage_lds + ((unsigned)(q % NS) * (unsigned)CH + (unsigned)base) * 16u;
+            lds_dma_16(desc + (gi < total ? gi : last_desc), (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+        }
+    };
+    for (int i = tid; i < npad * H; i += BT) tags[i] = -1;
+    if (tid < 2) s_miss[tid] = 0;
+    // descriptor chunks 0 .. 2 resident, chunk 3 in flight
+    for (int i = tid; i < 3 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
+    int pend_q = 3;      // the chunk whose pieces are in flight
+    int n_since = 0;     // store instructions this wave has certainly issued behind its last piece of chunk pend_q
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue_chunk(pend_q);
+    int s_cur = lev_start[0];
+    int t_cur = lev_start[1];
+    int t_nxt = nlev > 1 ? lev_start[2] : t_cur;
+    int4 d = s_cur + tid < t_cur ? dstage[(s_cur + tid) & smask] : make_int4(-1, -1, -1, 0);
+    for (int lv = 0; lv < nlev; ++lv) {
+        const int t_nn = lv + 2 < nlev ? lev_start[lv + 3] : t_nxt;
+        const int n_cur = t_cur - s_cur;   // events in this level (uniform)
+        const int n_nxt = t_nxt - t_cur;   // events in the next level
+        // the chunk the NEXT level ends in must be resident behind barrier 1 below: my pieces of it have landed once at most
+        // `n_since` memory instructions of mine are outstanding.  The slot the following chunk goes to held chunk
+        // need_q - 3: this level and the next one span chunks >= need_q - 2, and every wave is past the previous level.
+        const int need_q = t_nxt > 0 ? (t_nxt - 1) >> chs : 0;
+        while (need_q >= pend_q) {
+            wait_vm_at_most(n_since);
+            ++pend_q;
+            issue_chunk(pend_q);
+            n_since = 0;
+        }
+        if (tid == 0) s_miss[(lv + 1) & 1] = 0;
+        int a[CB], b[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) { a[c] = -1; b[c] = -1; }
+        unsigned miss = 0;
+        const bool mine = wave0 < n_cur;   // (scalar) some event of the level falls to this wave
+        if (mine) {  // read phase: both parents from the ring, tags and values requested together
+            const bool valid = (d.x >= 0) & (d.y >= 0);
+            // (an unused descriptor is {-1, -1, -1, 0}, a root has no other-parent bits: the addresses below are inside the ring anyway)
+            const int ia = (d.w & 1023) * H + ((((d.w >> 20) & 63) - 1) & hm);
+            const int ib = ((d.w >> 10) & 1023) * H + (((d.w >> 26) & 63) & hm);
+            const int ta = tags[ia];
+            const V va = vals[ia];
+            const int tb = tags[ib];
+            const V vb = vals[ib];
+            const bool ha = valid & (ta == d.y), hb = valid & (tb == d.z);
+            const int na = ha ? 0 : -1, nb = hb ? 0 : -1;
+            a[0] = va.x | na; a[1] = va.y | na; b[0] = vb.x | nb; b[1] = vb.y | nb;
+            if constexpr (CB == 4) { a[2] = va.z | na; a[3] = va.w | na; b[2] = vb.z | nb; b[3] = vb.w | nb; }
+            miss = ((valid & !ha) ? 1u : 0u) | ((valid & !hb) ? 2u : 0u);
+            if (miss) s_miss[lv & 1] = 1;
+        }
+        lds_barrier();  // every ring read of this level is done
+        int4 dn = make_int4(-1, -1, -1, 0);
+        if (wave0 < n_nxt && t_cur + tid < t_nxt) dn = dstage[(t_cur + tid) & smask];   // (requested with the miss flag: one LDS round trip)
+        if (s_miss[lv & 1]) {  // rare, workgroup-uniform: re-read rows from memory
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores ...
+            lds_barrier();                                     // ... before anyone re-reads
+            if (miss & 1u) load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)d.y * rowb), a);
+            if (miss & 2u) load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)d.z * rowb), b);
+        }
+        if (mine) {  // write phase
+            const bool act = d.x >= 0;
+            if (act) {
+                const int ce = d.w & 1023;
+                const int slot = ce * H + (((d.w >> 20) & 63) & hm);
+                const int own = ce - gcol0;
+                int v[CB];
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const int t = a[c] > b[c] ? a[c] : b[c];
+                    v[c] = (c == own) ? d.x : t;   // own entry (swirld.py:220)
+                }
+                store_cols<CB>(reinterpret_cast<int*>(Lcol + (size_t)(unsigned)d.x * rowb), v);
+                V vv;
+                vv.x = v[0]; vv.y = v[1];
+                if constexpr (CB == 4) { vv.z = v[2]; vv.w = v[3]; }
+                vals[slot] = vv;
+                tags[slot] = d.x;
+            }
+            n_since += __ballot(act) != 0 ? 1 : 0;   // (a store instruction with at least one lane has been issued)
+        }
+        lds_barrier();
+        s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn;
+        d = dn;
+    }
+}
+
 
 template <int NW, int C, int F, int H, bool WIDE>
 __global__ void __launch_bounds__(64 * NW + 64)

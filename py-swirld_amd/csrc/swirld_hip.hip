@@ -690,19 +690,17 @@ int ensure_sig_h(sw_ctx* c) {
     return SW_OK;
 }
 
-// geometry of the streaming can_see kernel for this member count
-struct CanseeCfg { int CB, MAXP, BT, H, chs; size_t lds; };
-CanseeCfg cansee_cfg(int npad, int want_H, int impl) {
+// geometry of the level-bucketed can_see kernel for this member count: CB columns per workgroup (one thread per event of a
+// level, the CB values of a row slice as one vector), npad threads, the deepest per-member ring that fits beside the staging ring
+struct CanseeCfg { int CB, H, chs; size_t lds; };
+CanseeCfg cansee_cfg(int npad, int want_H) {
     CanseeCfg g{};
-    if (npad <= 256 && impl == 3) { g.CB = 4; g.BT = 256; }      // 4 waves, 4 columns: npad/4 workgroups
-    else { g.CB = npad <= 256 ? 16 : 4; g.BT = 1024; }
-    const int EPB = g.BT / g.CB;
-    g.MAXP = std::max(1, npad / EPB);
+    g.CB = npad <= 512 ? 2 : 4;     // >= 160 workgroups up to 512 members, 256 at 1024
     int ch = 256;
     g.chs = 8;
     while (ch < npad) { ch <<= 1; g.chs++; }
-    int H = 8;
-    auto bytes = [&](int h) { return (size_t)4 * ch * 16 + ((size_t)npad * h * g.CB + (size_t)npad * h + 2) * sizeof(int); };
+    int H = 16;
+    auto bytes = [&](int h) { return (size_t)4 * ch * 16 + ((size_t)npad * h * (g.CB + 1) + 2) * sizeof(int); };
     while (H > 1 && bytes(H) > 158u * 1024u) H >>= 1;
     if (want_H >= 1 && want_H <= H && (want_H & (want_H - 1)) == 0) H = want_H;
     g.H = H;
@@ -710,31 +708,25 @@ CanseeCfg cansee_cfg(int npad, int want_H, int impl) {
     return g;
 }
 
-template <int CB, int MAXP, int BT>
+template <int CB>
 int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_cansee_stream<CB, MAXP, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_cansee_stream<CB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_cansee_stream<CB, MAXP, BT>), dim3(c->npad / CB), dim3(BT), g.lds, c->stream_cs,
+    hipLaunchKernelGGL((k_cansee_stream<CB>), dim3(c->npad / CB), dim3(c->npad), g.lds, c->stream_cs,
                        (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, g.H, g.chs);
     return SW_OK;
 }
 
 template <int NW>
 int launch_cansee(sw_ctx* c, int nlev, int /*pp*/) {
-    // the level-bucketed streaming kernel (SW_CANSEE_IMPL = 2 / 3: 1024 / 256 threads per workgroup at <= 256 members)
-    const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req, c->cansee_impl);
-    if (g.BT == 256 && g.MAXP == 1) CHK((launch_cansee_stream<4, 1, 256>(c, nlev, g)));
-    else if (g.BT == 256 && g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 256>(c, nlev, g)));
-    else if (g.BT == 256) CHK((launch_cansee_stream<4, 4, 256>(c, nlev, g)));
-    else if (g.CB == 16 && g.MAXP == 1) CHK((launch_cansee_stream<16, 1, 1024>(c, nlev, g)));
-    else if (g.CB == 16 && g.MAXP == 2) CHK((launch_cansee_stream<16, 2, 1024>(c, nlev, g)));
-    else if (g.CB == 16) CHK((launch_cansee_stream<16, 4, 1024>(c, nlev, g)));
-    else if (g.MAXP == 2) CHK((launch_cansee_stream<4, 2, 1024>(c, nlev, g)));
-    else CHK((launch_cansee_stream<4, 4, 1024>(c, nlev, g)));
+    // the level-bucketed kernel (the default beyond 256 members; SW_CANSEE_IMPL = 2 / 3 selects it below)
+    const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req);
+    if (g.CB == 2) CHK((launch_cansee_stream<2>(c, nlev, g)));
+    else CHK((launch_cansee_stream<4>(c, nlev, g)));
     c->ctr.kernel_launches++;
     HIPCHK(c, hipGetLastError());
     return SW_OK;
