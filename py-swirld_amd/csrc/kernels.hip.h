@@ -108,9 +108,31 @@ __device__ __forceinline__ void lanes_pair(uint32_t x, uint32_t& a, uint32_t& b)
 // events of one level are independent (parents have strictly smaller height,
 // swirld.py:117-120).
 // ---------------------------------------------------------------------------------
-__global__ void k_level_hist(const int* __restrict__ ht, int first, int K, int hmin, int* cnt) {
+// Will event e find its other-parent o in the level kernel's ring (depth H per member)?  o's slot is taken by its creator's
+// event H chain positions later — x — as soon as x's level is done; levels grow along a chain, so o has left the ring (or is
+// leaving it in e's very level) iff x belongs to this sweep and ht[x] <= ht[e].  Such an o is PINNED: its row slice also goes to
+// a small side table of the level kernel (slot o % SW_LEVEL_SIDE behind the ring), which is where e looks for it.
+#define SW_LEVEL_SIDE 256
+__device__ __forceinline__ bool level_op_pinned(int e, int o, int first, int K, int H, const int* __restrict__ ht, const int* __restrict__ cr,
+                                                const int* __restrict__ seq, const int* __restrict__ chain_start,
+                                                const int* __restrict__ chain_cnt, const int* __restrict__ chain_ev) {
+    if (o < first) return false;               // a row of an earlier launch: read from memory
+    const int co = cr[o];
+    const int p = seq[o] + H;
+    if (p >= chain_cnt[co]) return false;
+    const int x = chain_ev[chain_start[co] + p];
+    return x < first + K && ht[x] <= ht[e];
+}
+
+__global__ void k_level_hist(const int* __restrict__ ht, int first, int K, int hmin, int* cnt, const int* __restrict__ cr,
+                             const int* __restrict__ op, const int* __restrict__ seq, const int* __restrict__ chain_start,
+                             const int* __restrict__ chain_cnt, const int* __restrict__ chain_ev, int H, unsigned char* pin) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < K) atomicAdd(&cnt[ht[first + i] - hmin], 1);
+    if (i >= K) return;
+    const int e = first + i;
+    atomicAdd(&cnt[ht[e] - hmin], 1);
+    const int o = op[e];
+    if (o >= 0 && level_op_pinned(e, o, first, K, H, ht, cr, seq, chain_start, chain_cnt, chain_ev)) pin[o - first] = 1;
 }
 
 // single block exclusive scan, cnt[0..n) -> start[0..n], cursor zeroed
@@ -141,21 +163,31 @@ __global__ void k_level_scan(const int* __restrict__ cnt, int n, int* start, int
     if (tid == 0) start[n] = s_carry;
 }
 
-// desc.w packs what the ring kernel needs without further gathers:
-//   creator(e) [10 bits] | creator(op) << 10 | (seq(e) & 63) << 20 | (seq(op) & 63) << 26
-// where seq = position on the creator's self-parent chain (slot in the LDS ring).
+// desc = {event, self-parent, other-parent, w}; w packs the ring indices of the level kernel (k_cansee_stream, ring depth H):
+//   own slot cr(e)·H + seq(e) % H [14 bits]
+//   | where the other-parent is looked for << 14 [15 bits]: its ring slot cr(op)·H + seq(op) % H; the side table slot
+//     npad·H + 1 + op % SW_LEVEL_SIDE if it will have left the ring (level_op_pinned); npad·H = the all-absent slot of a root
+//   | (seq(e) % H == 0) << 29 (the self-parent's slot is own slot - 1, + H behind a wrap) | (e itself is pinned) << 30,
+// seq = position on the creator's self-parent chain.
 __global__ void k_level_scatter(const int* __restrict__ ht, const int* __restrict__ cr,
                                 const int* __restrict__ sp, const int* __restrict__ op,
                                 const int* __restrict__ seq, int first, int K,
-                                int hmin, const int* __restrict__ start, int* cursor, int4* desc) {
+                                int hmin, const int* __restrict__ start, int* cursor, int4* desc, int H, int npad,
+                                const int* __restrict__ chain_start, const int* __restrict__ chain_cnt, const int* __restrict__ chain_ev,
+                                const unsigned char* __restrict__ pin) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     int e = first + i;
     int lv = ht[e] - hmin;
     int slot = start[lv] + atomicAdd(&cursor[lv], 1);
     const int o = op[e];
-    int w = cr[e] | ((seq[e] & 63) << 20);
-    if (o >= 0) w |= (cr[o] << 10) | ((seq[o] & 63) << 26);
+    const int se = seq[e] % H;
+    int w = (cr[e] * H + se) | ((se == 0 ? 1 : 0) << 29) | ((int)pin[i] << 30);
+    int ib = npad * H;
+    if (o >= 0)
+        ib = level_op_pinned(e, o, first, K, H, ht, cr, seq, chain_start, chain_cnt, chain_ev) ? npad * H + 1 + (o & (SW_LEVEL_SIDE - 1))
+                                                                                               : cr[o] * H + seq[o] % H;
+    w |= ib << 14;
     desc[slot] = make_int4(e, sp[e], o, w);
 }
 
@@ -482,43 +514,97 @@ __device__ __forceinline__ void store_cols(int* ptr, const int (&v)[C]) {
 }
 
 // ---------------------------------------------------------------------------------
-// Level-bucketed can_see sweep (serves more than 256 members; tests/model: the oracle's own loop, level by level).
-// One workgroup = CB adjacent columns of every row, one THREAD per event of a DAG level (a level holds at most
-// one event per member: equal heights imply different creators), the CB values of a row slice as one vector:
-// one ring read per parent, one 4·CB-byte store per event.  Per member an LDS ring of the H most recent row
-// slices (slot = chain position mod H, tag = event id); the level descriptors stream through an LDS staging
-// ring (NS chunks of CH >= npad descriptors: a level spans at most two chunks).
+// Level-bucketed can_see sweep (serves more than 256 members): the oracle's own loop, one DAG level at a time.
+// One workgroup = CB adjacent columns of every row, one THREAD per event of a level (a level holds at most one
+// event per member: equal heights imply different creators), the CB values of a row slice as one vector: one ring
+// read per parent, one 4·CB-byte store per event.  Per member an LDS ring of its H most recent row slices (slot =
+// chain position mod H, tag = event id; slot npad·H = "absent", what a root's parents point at); the level
+// descriptors stream through an LDS staging ring (NS chunks of CH >= npad descriptors: a level spans at most two).
 //
-// Round 6 rewrite (the kernel is exposed beyond 512 members since the sweep no longer hides behind the round
-// loop there; profiles/r06_final_1024_pmc_summary.txt on the previous form — one thread per (event, column),
-// 4 passes of 256 events): 136 VALU instructions per wave and level on 16 waves = 0.9 us of pure issue per level,
-// and `s_waitcnt vmcnt(0)` in front of every store (the compiler cannot tell whether a parent value came from the
-// miss path's global load, and a descriptor chunk prefetched into registers is waited for through the same in-order
-// counter as the stores): 1.9 us per level, 10.4 ms per 2 M events at 1024 members.  Now
-//   * descriptor decode, tag compares and addresses are paid once per event, not once per (event, column); waves
-//     whose slice of the level is empty skip the level through scalar branches;
-//   * no drain of the global stores on the per-level path: the staging chunks arrive by LDS-DMA
+// Round 6 rewrite — the kernel is exposed beyond 512 members since the sweep no longer hides behind the round loop
+// there.  The previous form (one thread per (event, column), 4 passes of 256 events, two barriers) spent 136 VALU
+// instructions per wave and level on 16 waves, and `s_waitcnt vmcnt(0)` stood in front of every store (the compiler
+// cannot tell whether a parent value came from the miss path's global load, and a descriptor chunk prefetched into
+// registers is waited for through the same in-order counter as the stores): 1.9 us per level, 10.4 ms per 2 M
+// events at 1024 members (profiles/r06_final_1024_pmc_summary.txt).  Now a level is
+//     barrier -> ONE LDS round trip (tags and values of both parents, the miss flag of the previous level)
+//             -> a dozen VALU instructions -> ring write + row store + next descriptor -> barrier:
+//   * decode, tag compares and addresses once per event; the ring indices come precomputed in the descriptor;
+//     waves whose slice of the level is empty skip it through scalar branches;
+//   * no drain of the global stores on the per-level path: staging chunks arrive by LDS-DMA
 //     (`global_load_lds_dwordx4`, 1 KB pieces, no registers, invisible to the compiler's wait-count pass); a wave
 //     counts the store instructions it has certainly issued since its last piece and waits, when the chunk is first
-//     needed, for `vmcnt(that count)` — loads and stores retire in order, so normally it does not wait at all; the
-//     miss path (a parent row no longer in the ring: workgroup-wide drain + barrier, then re-read from L2) loads
-//     inside asm statements that wait for themselves;
-//   * tag and value of both parents are requested together, the next level's descriptor and the miss flag together
-//     behind the barrier: two LDS round trips and two LDS-only barriers per level.
+//     needed, for `vmcnt(that count)` — loads and stores retire in order, so normally it does not wait at all;
+//   * ONE barrier per level: a ring entry is written as {tag := -1, value, tag := event} and an other-parent is read
+//     as {tag, value, tag} (DS operations of a wave are performed in order), so a reader that races with a writer of
+//     the same level (the slot's member has an event H positions later in this very level) sees a tag mismatch — a
+//     miss; a self-parent's slot cannot be overwritten before the event itself is done;
+//   * misses are settled before the sweep starts: whether an other-parent will still be in the ring when its child's
+//     level comes is a property of the DAG (level_op_pinned, one look at the chain), so the level kernels mark such
+//     parents, their row slices also go to a side table of SW_LEVEL_SIDE slots behind the ring, and the child's
+//     descriptor points there; a parent of an earlier launch is read from memory on the spot (its row is complete);
+//   * what is left — two pinned parents alive in one side slot — defers the event: the thread raises a flag every wave
+//     reads with the next level's ring reads; in that case all waves drain their stores and meet, the deferred events
+//     take both parents from L2, and the level's ring reads are repeated.
 // ---------------------------------------------------------------------------------
+template <int CB> struct RingVec;
+template <> struct RingVec<2> { typedef int T __attribute__((ext_vector_type(2))); };
+template <> struct RingVec<4> { typedef int T __attribute__((ext_vector_type(4))); };
+
+template <int CB>
+__device__ __forceinline__ void ring_read_parents(unsigned tag_a, unsigned val_a, unsigned tag_b, unsigned val_b, unsigned flag,
+                                                  int& ta, typename RingVec<CB>::T& va, int& tb1, typename RingVec<CB>::T& vb, int& tb2, int& fl) {
+    // program order = LDS order: the second tag of the other-parent is read BEHIND its value
+    if constexpr (CB == 4)
+        asm volatile("ds_read_b32 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b32 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b32 %4, %8\n\tds_read_b32 %5, %10\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ta), "=&v"(va), "=&v"(tb1), "=&v"(vb), "=&v"(tb2), "=&v"(fl)
+                     : "v"(tag_a), "v"(val_a), "v"(tag_b), "v"(val_b), "v"(flag) : "memory");
+    else
+        asm volatile("ds_read_b32 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b32 %2, %8\n\tds_read_b64 %3, %9\n\tds_read_b32 %4, %8\n\tds_read_b32 %5, %10\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ta), "=&v"(va), "=&v"(tb1), "=&v"(vb), "=&v"(tb2), "=&v"(fl)
+                     : "v"(tag_a), "v"(val_a), "v"(tag_b), "v"(val_b), "v"(flag) : "memory");
+}
+
+// (LDS words by byte address: a `volatile int*` into LDS becomes a FLAT access with `s_waitcnt vmcnt(0)` behind it)
+__device__ __forceinline__ void lds_set(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ int lds_get(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// a side slot takes ONE writer per phase (the {tag, value, tag} protocol is single-writer): the first claimant of a stamp wins
+__device__ __forceinline__ bool lds_claim(unsigned addr, int stamp) {
+    int old;
+    asm volatile("ds_max_rtn_i32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old) : "v"(addr), "v"(stamp) : "memory");
+    return old < stamp;
+}
+
+template <int CB>
+__device__ __forceinline__ void ring_write(unsigned tag_addr, unsigned val_addr, typename RingVec<CB>::T v, int e) {
+    const int none = -1;
+    if constexpr (CB == 4)
+        asm volatile("ds_write_b32 %0, %1\n\tds_write_b128 %2, %3\n\tds_write_b32 %0, %4" :: "v"(tag_addr), "v"(none), "v"(val_addr), "v"(v), "v"(e) : "memory");
+    else
+        asm volatile("ds_write_b32 %0, %1\n\tds_write_b64 %2, %3\n\tds_write_b32 %0, %4" :: "v"(tag_addr), "v"(none), "v"(val_addr), "v"(v), "v"(e) : "memory");
+}
+
 template <int CB>
 __global__ void __launch_bounds__(1024)
 k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
-                int* L, int npad, int H, int chs) {
-    typedef typename ColVec<CB>::T V;
+                int* L, int npad, int H, int chs, int first_event, int dbg, u64* dbgp) {
+    typedef typename RingVec<CB>::T V;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int NS = 4;
     const int CH = 1 << chs;  // descriptors per staging chunk (power of two, >= npad = blockDim.x)
     const int smask = NS * CH - 1;
+    const int nslot = npad * H;                              // ring slots; slot nslot = absent; behind it the side table
+    const int nall = nslot + 1 + SW_LEVEL_SIDE;
     int4* dstage = (int4*)smem;                              // [NS * CH], descriptor i at i & smask
-    V* vals = (V*)(dstage + (size_t)NS * CH);                // [npad][H]
-    int* tags = (int*)(vals + (size_t)npad * H);             // [npad][H]
-    int* s_miss = tags + (size_t)npad * H;                   // [2]
+    V* vals = (V*)(dstage + (size_t)NS * CH);                // [nall]
+    int* tags = (int*)(vals + (size_t)nall);                 // [nall]
+    int* side_lock = tags + (size_t)nall;                    // [SW_LEVEL_SIDE]: the last phase that wrote the side slot (lds_claim)
+    int* s_flag = side_lock + SW_LEVEL_SIDE;                 // [3]: some event of level lv was deferred (slot lv % 3); by byte address only
     const int tid = threadIdx.x, BT = blockDim.x;
     const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);   // first event slot of this wave
     // XCD-aware column groups: workgroup b runs on XCD b % 8 (observed); give each XCD a
@@ -528,10 +614,12 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     const int gcol0 = grp * CB;
     char* const Lcol = reinterpret_cast<char*>(L + gcol0);
     const unsigned rowb = (unsigned)npad * 4u;
-    const int hm = H - 1;
     const int total = lev_start[nlev];
     const int last_desc = total > 0 ? total - 1 : 0;
     const unsigned stage_lds = (unsigned)(size_t)dstage;     // (the low half of a generic LDS address is the LDS byte address)
+    const unsigned vals_lds = (unsigned)(size_t)vals, tags_lds = (unsigned)(size_t)tags, flag_lds = (unsigned)(size_t)s_flag;
+    const unsigned lock_lds = (unsigned)(size_t)side_lock;
+    const int own_lo = gcol0 * H;                            // own slots of the members whose columns these are: [own_lo, own_lo + CB·H)
     // this wave's pieces of chunk q -> slot q % NS (entries beyond the last descriptor hold a copy of it: never read)
     auto issue_chunk = [&](int q) {
         for (int base = wave0; base < CH; base += BT) {
@@ -540,8 +628,12 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
             lds_dma_16(desc + (gi < total ? gi : last_desc), (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
         }
     };
-    for (int i = tid; i < npad * H; i += BT) tags[i] = -1;
-    if (tid < 2) s_miss[tid] = 0;
+    V none;
+    none.x = -1; none.y = -1;
+    if constexpr (CB == 4) { none.z = -1; none.w = -1; }
+    for (int i = tid; i < nall; i += BT) { tags[i] = -1; vals[i] = none; }
+    if (tid < 3) s_flag[tid] = 0;
+    for (int i = tid; i < SW_LEVEL_SIDE; i += BT) side_lock[i] = 0;
     // descriptor chunks 0 .. 2 resident, chunk 3 in flight
     for (int i = tid; i < 3 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
     int pend_q = 3;      // the chunk whose pieces are in flight
@@ -551,79 +643,138 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     int s_cur = lev_start[0];
     int t_cur = lev_start[1];
     int t_nxt = nlev > 1 ? lev_start[2] : t_cur;
+    int t_nn = nlev > 2 ? lev_start[3] : t_nxt;
     int4 d = s_cur + tid < t_cur ? dstage[(s_cur + tid) & smask] : make_int4(-1, -1, -1, 0);
-    for (int lv = 0; lv < nlev; ++lv) {
-        const int t_nn = lv + 2 < nlev ? lev_start[lv + 3] : t_nxt;
+    int4 dprev = make_int4(-1, -1, -1, 0);   // my event of the previous level, kept for the case it was deferred
+    bool deferred = false;
+    int f_prev = 2, f_cur = 0, f_nxt = 1;    // flag slots of levels lv - 1, lv, lv + 1 (lv % 3)
+    const bool stamp = dbgp != nullptr && blockIdx.x == 0 && wave0 == 0;
+    u64 ph[4] = {0, 0, 0, 0};
+    // levels 0 .. nlev - 1, then one empty level that serves the deferred events of the last one
+    for (int lv = 0; lv <= nlev; ++lv) {
+        u64 c0 = 0, c1 = 0, c2 = 0;
+        if (stamp) c0 = clock64();
+        const int t_n3 = lv + 4 <= nlev ? lev_start[lv + 4] : t_nn;   // (end of level lv + 3: the next iteration's t_nn)
         const int n_cur = t_cur - s_cur;   // events in this level (uniform)
         const int n_nxt = t_nxt - t_cur;   // events in the next level
-        // the chunk the NEXT level ends in must be resident behind barrier 1 below: my pieces of it have landed once at most
-        // `n_since` memory instructions of mine are outstanding.  The slot the following chunk goes to held chunk
-        // need_q - 3: this level and the next one span chunks >= need_q - 2, and every wave is past the previous level.
-        const int need_q = t_nxt > 0 ? (t_nxt - 1) >> chs : 0;
+        // Level lv + 1 fetches the descriptors of level lv + 2: the chunk that level ends in must have landed — every wave's
+        // pieces of it — behind THIS level's barrier, so each wave makes sure of its own pieces here: they have landed once at
+        // most `n_since` memory instructions of the wave are outstanding.  The slot the following chunk goes to held chunk
+        // need_q - 3: this level's fetches (level lv + 1's descriptors) touch chunks >= need_q - 2 (two levels span at most
+        // 2 CH descriptors), and every wave is past the previous level's barrier, i.e. past its fetches.
+        const int need_q = t_nn > 0 ? (t_nn - 1) >> chs : 0;
         while (need_q >= pend_q) {
             wait_vm_at_most(n_since);
             ++pend_q;
             issue_chunk(pend_q);
             n_since = 0;
         }
-        if (tid == 0) s_miss[(lv + 1) & 1] = 0;
-        int a[CB], b[CB];
-#pragma unroll
-        for (int c = 0; c < CB; ++c) { a[c] = -1; b[c] = -1; }
-        unsigned miss = 0;
+        if (tid == 0) lds_set(flag_lds + 4u * (unsigned)f_nxt, 0);   // (level lv - 2's flag: read by everybody before the last barrier, raised again behind this level's)
         const bool mine = wave0 < n_cur;   // (scalar) some event of the level falls to this wave
-        if (mine) {  // read phase: both parents from the ring, tags and values requested together
-            const bool valid = (d.x >= 0) & (d.y >= 0);
-            // (an unused descriptor is {-1, -1, -1, 0}, a root has no other-parent bits: the addresses below are inside the ring anyway)
-            const int ia = (d.w & 1023) * H + ((((d.w >> 20) & 63) - 1) & hm);
-            const int ib = ((d.w >> 10) & 1023) * H + (((d.w >> 26) & 63) & hm);
-            const int ta = tags[ia];
-            const V va = vals[ia];
-            const int tb = tags[ib];
-            const V vb = vals[ib];
-            const bool ha = valid & (ta == d.y), hb = valid & (tb == d.z);
-            const int na = ha ? 0 : -1, nb = hb ? 0 : -1;
-            a[0] = va.x | na; a[1] = va.y | na; b[0] = vb.x | nb; b[1] = vb.y | nb;
-            if constexpr (CB == 4) { a[2] = va.z | na; a[3] = va.w | na; b[2] = vb.z | nb; b[3] = vb.w | nb; }
-            miss = ((valid & !ha) ? 1u : 0u) | ((valid & !hb) ? 2u : 0u);
-            if (miss) s_miss[lv & 1] = 1;
-        }
-        lds_barrier();  // every ring read of this level is done
-        int4 dn = make_int4(-1, -1, -1, 0);
-        if (wave0 < n_nxt && t_cur + tid < t_nxt) dn = dstage[(t_cur + tid) & smask];   // (requested with the miss flag: one LDS round trip)
-        if (s_miss[lv & 1]) {  // rare, workgroup-uniform: re-read rows from memory
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores ...
-            lds_barrier();                                     // ... before anyone re-reads
-            if (miss & 1u) load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)d.y * rowb), a);
-            if (miss & 2u) load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)d.z * rowb), b);
-        }
-        if (mine) {  // write phase
-            const bool act = d.x >= 0;
-            if (act) {
-                const int ce = d.w & 1023;
-                const int slot = ce * H + (((d.w >> 20) & 63) & hm);
-                const int own = ce - gcol0;
-                int v[CB];
+        const int slot = d.w & 0x3fff;
+        const int ib = (d.w >> 14) & 0x7fff;
+        const int ia = slot - 1 + ((d.w >> 29) & 1) * H;
+        int ta = 0, tb1 = 0, tb2 = 0, fl;
+        V va = none, vb = none;
+        if (mine) ring_read_parents<CB>(tags_lds + 4u * (unsigned)ia, vals_lds + (unsigned)sizeof(V) * (unsigned)ia, tags_lds + 4u * (unsigned)ib,
+                                        vals_lds + (unsigned)sizeof(V) * (unsigned)ib, flag_lds + 4u * (unsigned)f_prev, ta, va, tb1, vb, tb2, fl);
+        else fl = lds_get(flag_lds + 4u * (unsigned)f_prev);
+        if (__builtin_amdgcn_readfirstlane(fl)) {
+            // rare: events of level lv - 1 were deferred.  Every wave drains its stores, then the deferred events take
+            // both parents from L2 (their rows were stored before this point, by whichever wave), then the ring is read again.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (deferred) {
+                int pa[CB], pb[CB], v[CB];
+                load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)dprev.y * rowb), pa);
+                load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)dprev.z * rowb), pb);
+                const int pslot = dprev.w & 0x3fff;
+                const int rel = pslot - own_lo;
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
-                    const int t = a[c] > b[c] ? a[c] : b[c];
-                    v[c] = (c == own) ? d.x : t;   // own entry (swirld.py:220)
+                    const int t = pa[c] > pb[c] ? pa[c] : pb[c];
+                    v[c] = (rel >= c * H && rel < (c + 1) * H) ? dprev.x : t;   // own entry (swirld.py:220)
                 }
-                store_cols<CB>(reinterpret_cast<int*>(Lcol + (size_t)(unsigned)d.x * rowb), v);
+                if (!(dbg & 1)) store_cols<CB>(reinterpret_cast<int*>(Lcol + (size_t)(unsigned)dprev.x * rowb), v);
                 V vv;
                 vv.x = v[0]; vv.y = v[1];
                 if constexpr (CB == 4) { vv.z = v[2]; vv.w = v[3]; }
-                vals[slot] = vv;
-                tags[slot] = d.x;
+                ring_write<CB>(tags_lds + 4u * (unsigned)pslot, vals_lds + (unsigned)sizeof(V) * (unsigned)pslot, vv, dprev.x);
+                if ((dprev.w >> 30) & 1) {
+                    const unsigned sd = (unsigned)(dprev.x & (SW_LEVEL_SIDE - 1)), ps = (unsigned)(nslot + 1) + sd;
+                    if (lds_claim(lock_lds + 4u * sd, 2 * lv + 1)) ring_write<CB>(tags_lds + 4u * ps, vals_lds + (unsigned)sizeof(V) * ps, vv, dprev.x);
+                }
             }
-            n_since += __ballot(act) != 0 ? 1 : 0;   // (a store instruction with at least one lane has been issued)
+            n_since = 0;   // (the drain: nothing of mine is outstanding but these stores)
+            lds_barrier();
+            if (mine) ring_read_parents<CB>(tags_lds + 4u * (unsigned)ia, vals_lds + (unsigned)sizeof(V) * (unsigned)ia, tags_lds + 4u * (unsigned)ib,
+                                            vals_lds + (unsigned)sizeof(V) * (unsigned)ib, flag_lds + 4u * (unsigned)f_prev, ta, va, tb1, vb, tb2, fl);
         }
+        if (stamp) c1 = clock64();
+        int4 dn = make_int4(-1, -1, -1, 0);
+        if (wave0 < n_nxt && t_cur + tid < t_nxt) dn = dstage[(t_cur + tid) & smask];
+        deferred = false;
+        if (mine) {
+            const bool act = d.x >= 0;
+            bool ma = act & (ta != d.y), mb = act & !((tb1 == d.z) & (tb2 == d.z));
+            if (__ballot(ma | mb)) {   // a parent of an earlier launch: its row is complete in memory
+                if (ma & (d.y < first_event)) {
+                    int t[CB];
+                    load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)d.y * rowb), t);
+                    va.x = t[0]; va.y = t[1];
+                    if constexpr (CB == 4) { va.z = t[2]; va.w = t[3]; }
+                    ma = false;
+                }
+                if (mb & (d.z < first_event)) {
+                    int t[CB];
+                    load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)d.z * rowb), t);
+                    vb.x = t[0]; vb.y = t[1];
+                    if constexpr (CB == 4) { vb.z = t[2]; vb.w = t[3]; }
+                    mb = false;
+                }
+                n_since = 0;   // (the loads wait for everything of this wave)
+            }
+            bool hit = !(ma | mb);
+            if (dbg & 2) hit = true;
+            deferred = act & !hit;
+            if (deferred) lds_set(flag_lds + 4u * (unsigned)f_cur, 1);
+            const bool go = act & hit;
+            if (go) {
+                V vv;
+                vv.x = va.x > vb.x ? va.x : vb.x;
+                vv.y = va.y > vb.y ? va.y : vb.y;
+                if constexpr (CB == 4) { vv.z = va.z > vb.z ? va.z : vb.z; vv.w = va.w > vb.w ? va.w : vb.w; }
+                const int rel = slot - own_lo;
+                if (__ballot((unsigned)rel < (unsigned)(CB * H))) {   // own entry (swirld.py:220): a member of these columns
+                    if (rel >= 0 && rel < H) vv.x = d.x;
+                    if (rel >= H && rel < 2 * H) vv.y = d.x;
+                    if constexpr (CB == 4) {
+                        if (rel >= 2 * H && rel < 3 * H) vv.z = d.x;
+                        if (rel >= 3 * H && rel < 4 * H) vv.w = d.x;
+                    }
+                }
+                if (!(dbg & 1)) *reinterpret_cast<V*>(Lcol + (size_t)(unsigned)d.x * rowb) = vv;
+                ring_write<CB>(tags_lds + 4u * (unsigned)slot, vals_lds + (unsigned)sizeof(V) * (unsigned)slot, vv, d.x);
+                if (__ballot((d.w >> 30) & 1)) {   // pinned: a child will look for this row slice after it has left the ring
+                    if ((d.w >> 30) & 1) {   // (a pinned event that loses its side slot to another one of this level: its child defers)
+                        const unsigned sd = (unsigned)(d.x & (SW_LEVEL_SIDE - 1)), ps = (unsigned)(nslot + 1) + sd;
+                        if (lds_claim(lock_lds + 4u * sd, 2 * lv + 2)) ring_write<CB>(tags_lds + 4u * ps, vals_lds + (unsigned)sizeof(V) * ps, vv, d.x);
+                    }
+                }
+            }
+            n_since += __ballot(go) != 0 ? 1 : 0;   // (a store instruction with at least one lane has certainly been issued: a LOWER bound)
+        }
+        if (stamp) c2 = clock64();
         lds_barrier();
-        s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn;
+        if (stamp) { const u64 c3 = clock64(); ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += 1; }
+        s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn; t_nn = t_n3;
+        dprev = d;
         d = dn;
+        const int f = f_prev; f_prev = f_cur; f_cur = f_nxt; f_nxt = f;
     }
+    if (stamp && (tid & 63) == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&dbgp[8 + i], ph[i]);
 }
-
 
 template <int NW, int C, int F, int H, bool WIDE>
 __global__ void __launch_bounds__(64 * NW + 64)

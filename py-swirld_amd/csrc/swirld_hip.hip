@@ -189,6 +189,7 @@ struct sw_ctx {
 
     // device: levels
     DBuf<int32_t> d_lev_cnt, d_lev_start, d_lev_cursor;
+    DBuf<uint8_t> d_lev_pin;     // level sweep: events whose row slice a child looks for after it has left the ring (k_level_hist)
     DBuf<int4> d_desc;
 
     // device: rounds
@@ -254,6 +255,7 @@ struct sw_ctx {
     int BATCH = 24;    // loop iterations between host checks
     int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers: k_cansee_chunks / k_cansee_flow); 2 / 3 = level-bucketed sweep (k_cansee_stream, 1024 / 256 threads: the default beyond 256 members)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
+    int stream_dbg = 0;   // SW_STREAM_DBG (measurement only, WRONG results): 1 = the level sweep stores no rows, 2 = it takes ring misses for hits, 4 = it stores into 64 MB
     int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced, one wave per slot (unit stake only), 2 = bit-sliced two-level search (k_tally_tree)
     bool tally_auto = true;   // SW_TALLY_IMPL not set: large calls of ~256-member hashgraphs without strongly skewed activity use 2
@@ -700,7 +702,7 @@ CanseeCfg cansee_cfg(int npad, int want_H) {
     g.chs = 8;
     while (ch < npad) { ch <<= 1; g.chs++; }
     int H = 16;
-    auto bytes = [&](int h) { return (size_t)4 * ch * 16 + ((size_t)npad * h * (g.CB + 1) + 2) * sizeof(int); };
+    auto bytes = [&](int h) { return (size_t)4 * ch * 16 + ((size_t)npad * h + 1 + SW_LEVEL_SIDE) * (g.CB + 1) * sizeof(int) + SW_LEVEL_SIDE * sizeof(int) + 16; };
     while (H > 1 && bytes(H) > 158u * 1024u) H >>= 1;
     if (want_H >= 1 && want_H <= H && (want_H & (want_H - 1)) == 0) H = want_H;
     g.H = H;
@@ -709,7 +711,7 @@ CanseeCfg cansee_cfg(int npad, int want_H) {
 }
 
 template <int CB>
-int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
+int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g, int64_t first_event) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k_cansee_stream<CB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -717,16 +719,16 @@ int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g) {
         attr_set = true;
     }
     hipLaunchKernelGGL((k_cansee_stream<CB>), dim3(c->npad / CB), dim3(c->npad), g.lds, c->stream_cs,
-                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, g.H, g.chs);
+                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, g.H, g.chs, (int)first_event, c->stream_dbg, c->d_flow_dbg);
     return SW_OK;
 }
 
 template <int NW>
-int launch_cansee(sw_ctx* c, int nlev, int /*pp*/) {
+int launch_cansee(sw_ctx* c, int nlev, int64_t first_event) {
     // the level-bucketed kernel (the default beyond 256 members; SW_CANSEE_IMPL = 2 / 3 selects it below)
     const CanseeCfg g = cansee_cfg(c->npad, c->ring_H_req);
-    if (g.CB == 2) CHK((launch_cansee_stream<2>(c, nlev, g)));
-    else CHK((launch_cansee_stream<4>(c, nlev, g)));
+    if (g.CB == 2) CHK((launch_cansee_stream<2>(c, nlev, g, first_event)));
+    else CHK((launch_cansee_stream<4>(c, nlev, g, first_event)));
     c->ctr.kernel_launches++;
     HIPCHK(c, hipGetLastError());
     return SW_OK;
@@ -1365,6 +1367,7 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         CHK(dgrow(c, c->d_lev_start, max_nlev + 1, 0));
         CHK(dgrow(c, c->d_lev_cursor, max_nlev, 0));
         CHK(dgrow(c, c->d_desc, max_k, 0));
+        CHK(dgrow(c, c->d_lev_pin, max_k, 0));
     }
     while ((int)c->cs_events.size() < S) {
         hipEvent_t e;
@@ -1462,15 +1465,21 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
             CHK(launch_cansee_flow<NW>(c, i, a));
         } else {
             HIPCHK(c, hipMemsetAsync(c->d_lev_cnt.p, 0, nlevs[i] * sizeof(int32_t), cs));
+            HIPCHK(c, hipMemsetAsync(c->d_lev_pin.p, 0, (size_t)k, cs));
             const int eb = (int)((k + 255) / 256);
-            hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (int)a, (int)k, hmins[i], c->d_lev_cnt.p);
+            const int ringH = cansee_cfg(np, c->ring_H_req).H;
+            hipLaunchKernelGGL(k_level_hist, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (int)a, (int)k, hmins[i], c->d_lev_cnt.p,
+                               (const int*)c->d_cr.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
+                               (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, ringH, c->d_lev_pin.p);
             hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, cs, (const int*)c->d_lev_cnt.p, nlevs[i], c->d_lev_start.p, c->d_lev_cursor.p);
             hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
                                (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)a, (int)k, hmins[i],
-                               (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p);
+                               (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p, ringH, np,
+                               (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p,
+                               (const unsigned char*)c->d_lev_pin.p);
             c->ctr.kernel_launches += 3;
             scs = span_begin(c, cs);
-            CHK(launch_cansee<NW>(c, nlevs[i], i));
+            CHK(launch_cansee<NW>(c, nlevs[i], a));
         }
         span_end(c, scs, cs);
         if (c->profiling) cansee_spans.push_back(scs);
@@ -2296,6 +2305,7 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (c->elect_cg != 64 && c->elect_cg != 128 && c->elect_cg != 256) knob_err = "SW_ELECT_CG: 64, 128 or 256";
     knob("SW_GALLOP", 0, 255, &c->gallop_after);
     knob("SW_SKIP", 0, 32, &c->skip);
+    knob("SW_STREAM_DBG", 0, 7, &c->stream_dbg);
     knob("SW_RING_H", 0, 64, &c->ring_H_req);      // ring depth of the level-bucketed sweep (0 = automatic)
     if (!knob_err.empty()) {
         delete c;
@@ -2303,8 +2313,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     }
     c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
     if (c->debug_timing) {
-        if (hipMalloc(&c->d_flow_dbg, 8 * sizeof(u64)) != hipSuccess) c->d_flow_dbg = nullptr;
-        else (void)hipMemset(c->d_flow_dbg, 0, 8 * sizeof(u64));
+        if (hipMalloc(&c->d_flow_dbg, 16 * sizeof(u64)) != hipSuccess) c->d_flow_dbg = nullptr;
+        else (void)hipMemset(c->d_flow_dbg, 0, 16 * sizeof(u64));
     }
     if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
         c->dbg_minor = atoi(getenv("SW_DEBUG_CLOCKS")) >= 2 ? 0 : 1;
@@ -2436,8 +2446,11 @@ int sw_destroy(sw_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->debug_timing && c->d_flow_dbg) {
-        u64 d[8] = {0};
+        u64 d[16] = {0};
         (void)hipMemcpy(d, c->d_flow_dbg, sizeof d, hipMemcpyDeviceToHost);
+        if (d[11])
+            fprintf(stderr, "[sw] level sweep, workgroup 0 / wave 0, clocks per level over %llu levels: top + ring reads (+ deferred events) %.0f, compute + writes %.0f, barrier %.0f\n",
+                    d[11], (double)d[8] / d[11], (double)d[9] / d[11], (double)d[10] / d[11]);
         fprintf(stderr, "[sw] dataflow sweep, column 0: %llu events, %llu rows re-read from memory, %llu starved lane-trips, %llu wave-trips over %llu wave runs "
                 "(%.1f trips per wave run), loader passes %llu (+%llu idle)\n", d[0], d[1], d[2], d[3], d[6], d[6] ? (double)d[3] / (double)d[6] : 0.0, d[4], d[5]);
         (void)hipFree(c->d_flow_dbg);
@@ -2456,7 +2469,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S); dfree(c->d_finlist);
     if (c->d_fin) (void)hipFree(c->d_fin);
-    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start);
+    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start); dfree(c->d_lev_pin);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
