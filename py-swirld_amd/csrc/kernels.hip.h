@@ -112,7 +112,7 @@ __device__ __forceinline__ void lanes_pair(uint32_t x, uint32_t& a, uint32_t& b)
 // event H chain positions later — x — as soon as x's level is done; levels grow along a chain, so o has left the ring (or is
 // leaving it in e's very level) iff x belongs to this sweep and ht[x] <= ht[e].  Such an o is PINNED: its row slice also goes to
 // a small side table of the level kernel (slot o % SW_LEVEL_SIDE behind the ring), which is where e looks for it.
-#define SW_LEVEL_SIDE 256
+#define SW_LEVEL_SIDE 512
 __device__ __forceinline__ bool level_op_pinned(int e, int o, int first, int K, int H, const int* __restrict__ ht, const int* __restrict__ cr,
                                                 const int* __restrict__ seq, const int* __restrict__ chain_start,
                                                 const int* __restrict__ chain_cnt, const int* __restrict__ chain_ev) {
@@ -165,30 +165,48 @@ __global__ void k_level_scan(const int* __restrict__ cnt, int n, int* start, int
 
 // desc = {event, self-parent, other-parent, w}; w packs the ring indices of the level kernel (k_cansee_stream, ring depth H):
 //   own slot cr(e)·H + seq(e) % H [14 bits]
-//   | where the other-parent is looked for << 14 [15 bits]: its ring slot cr(op)·H + seq(op) % H; the side table slot
-//     npad·H + 1 + op % SW_LEVEL_SIDE if it will have left the ring (level_op_pinned); npad·H = the all-absent slot of a root
+//   | where the other-parent is looked for << 14 [15 bits]: its ring slot cr(op)·H + seq(op) % H; its side table slot
+//     npad·H + 1 + rank(op) % SW_LEVEL_SIDE if it will have left the ring (level_op_pinned; filled in by k_level_patch);
+//     npad·H = the all-absent slot of a root
 //   | (seq(e) % H == 0) << 29 (the self-parent's slot is own slot - 1, + H behind a wrap) | (e itself is pinned) << 30,
-// seq = position on the creator's self-parent chain.
+// seq = position on the creator's self-parent chain.  The PINNED events of a level stand at the head of its descriptors
+// (they are dealt from the front, the others from the back), so the pinned event at position k of level lv has
+// rank = pinbase[lv] + k among all pinned events of the sweep, level by level: the side table is written round-robin
+// and an entry lives until SW_LEVEL_SIDE later pinned events have been written — hundreds of levels.
 __global__ void k_level_scatter(const int* __restrict__ ht, const int* __restrict__ cr,
                                 const int* __restrict__ sp, const int* __restrict__ op,
                                 const int* __restrict__ seq, int first, int K,
-                                int hmin, const int* __restrict__ start, int* cursor, int4* desc, int H, int npad,
-                                const int* __restrict__ chain_start, const int* __restrict__ chain_cnt, const int* __restrict__ chain_ev,
-                                const unsigned char* __restrict__ pin) {
+                                int hmin, const int* __restrict__ start, int* cfront, int* cback, int4* desc, int H, int npad,
+                                const unsigned char* __restrict__ pin, int* __restrict__ pos) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K) return;
     int e = first + i;
     int lv = ht[e] - hmin;
-    int slot = start[lv] + atomicAdd(&cursor[lv], 1);
+    const int pinned = pin[i];
+    const int slot = pinned ? start[lv] + atomicAdd(&cfront[lv], 1) : start[lv + 1] - 1 - atomicAdd(&cback[lv], 1);
+    pos[i] = slot;
     const int o = op[e];
     const int se = seq[e] % H;
-    int w = (cr[e] * H + se) | ((se == 0 ? 1 : 0) << 29) | ((int)pin[i] << 30);
-    int ib = npad * H;
-    if (o >= 0)
-        ib = level_op_pinned(e, o, first, K, H, ht, cr, seq, chain_start, chain_cnt, chain_ev) ? npad * H + 1 + (o & (SW_LEVEL_SIDE - 1))
-                                                                                               : cr[o] * H + seq[o] % H;
-    w |= ib << 14;
+    int w = (cr[e] * H + se) | ((se == 0 ? 1 : 0) << 29) | (pinned << 30);
+    w |= (o >= 0 ? cr[o] * H + seq[o] % H : npad * H) << 14;
     desc[slot] = make_int4(e, sp[e], o, w);
+}
+
+// the children of pinned events look for them in the side table
+__global__ void k_level_patch(const int* __restrict__ ht, const int* __restrict__ cr, const int* __restrict__ op,
+                              const int* __restrict__ seq, int first, int K, int hmin, const int* __restrict__ start,
+                              const int* __restrict__ pinbase, int4* desc, int H, int npad,
+                              const int* __restrict__ chain_start, const int* __restrict__ chain_cnt, const int* __restrict__ chain_ev,
+                              const int* __restrict__ pos) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int e = first + i;
+    const int o = op[e];
+    if (o < 0 || !level_op_pinned(e, o, first, K, H, ht, cr, seq, chain_start, chain_cnt, chain_ev)) return;
+    const int lvo = ht[o] - hmin;
+    const int rank = pinbase[lvo] + pos[o - first] - start[lvo];
+    int* w = &desc[pos[i]].w;
+    *w = (*w & ~(0x7fff << 14)) | ((npad * H + 1 + (rank & (SW_LEVEL_SIDE - 1))) << 14);
 }
 
 
@@ -541,9 +559,10 @@ __device__ __forceinline__ void store_cols(int* ptr, const int (&v)[C]) {
 //     miss; a self-parent's slot cannot be overwritten before the event itself is done;
 //   * misses are settled before the sweep starts: whether an other-parent will still be in the ring when its child's
 //     level comes is a property of the DAG (level_op_pinned, one look at the chain), so the level kernels mark such
-//     parents, their row slices also go to a side table of SW_LEVEL_SIDE slots behind the ring, and the child's
-//     descriptor points there; a parent of an earlier launch is read from memory on the spot (its row is complete);
-//   * what is left — two pinned parents alive in one side slot — defers the event: the thread raises a flag every wave
+//     parents, their row slices also go to a side table of SW_LEVEL_SIDE slots behind the ring — written round-robin
+//     in the order the pinned events come (k_level_scatter) — and the child's descriptor points there; a parent of
+//     an earlier launch is read from memory on the spot (its row is complete);
+//   * what is left — a pinned parent still wanted SW_LEVEL_SIDE pinned events later — defers the event: the thread raises a flag every wave
 //     reads with the next level's ring reads; in that case all waves drain their stores and meet, the deferred events
 //     take both parents from L2, and the level's ring reads are repeated.
 // ---------------------------------------------------------------------------------
@@ -591,7 +610,7 @@ __device__ __forceinline__ void ring_write(unsigned tag_addr, unsigned val_addr,
 
 template <int CB>
 __global__ void __launch_bounds__(1024)
-k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, int nlev,
+k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, const int* __restrict__ lev_pinbase, int nlev,
                 int* L, int npad, int H, int chs, int first_event, int dbg, u64* dbgp) {
     typedef typename RingVec<CB>::T V;
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -645,16 +664,18 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     int t_nxt = nlev > 1 ? lev_start[2] : t_cur;
     int t_nn = nlev > 2 ? lev_start[3] : t_nxt;
     int4 d = s_cur + tid < t_cur ? dstage[(s_cur + tid) & smask] : make_int4(-1, -1, -1, 0);
+    int pb_prev = 0, pb_cur = lev_pinbase[0];   // pinned events of the sweep in front of levels lv - 1, lv (their first side-table ranks)
     int4 dprev = make_int4(-1, -1, -1, 0);   // my event of the previous level, kept for the case it was deferred
     bool deferred = false;
     int f_prev = 2, f_cur = 0, f_nxt = 1;    // flag slots of levels lv - 1, lv, lv + 1 (lv % 3)
     const bool stamp = dbgp != nullptr && blockIdx.x == 0 && wave0 == 0;
-    u64 ph[4] = {0, 0, 0, 0};
+    u64 ph[5] = {0, 0, 0, 0, 0};
     // levels 0 .. nlev - 1, then one empty level that serves the deferred events of the last one
     for (int lv = 0; lv <= nlev; ++lv) {
         u64 c0 = 0, c1 = 0, c2 = 0;
         if (stamp) c0 = clock64();
         const int t_n3 = lv + 4 <= nlev ? lev_start[lv + 4] : t_nn;   // (end of level lv + 3: the next iteration's t_nn)
+        const int pb_nxt = lev_pinbase[lv + 1 <= nlev ? lv + 1 : nlev];
         const int n_cur = t_cur - s_cur;   // events in this level (uniform)
         const int n_nxt = t_nxt - t_cur;   // events in the next level
         // Level lv + 1 fetches the descriptors of level lv + 2: the chunk that level ends in must have landed — every wave's
@@ -684,6 +705,7 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
             // both parents from L2 (their rows were stored before this point, by whichever wave), then the ring is read again.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
+            if (stamp) ph[4] += 1;
             if (deferred) {
                 int pa[CB], pb[CB], v[CB];
                 load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)dprev.y * rowb), pa);
@@ -701,7 +723,7 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
                 if constexpr (CB == 4) { vv.z = v[2]; vv.w = v[3]; }
                 ring_write<CB>(tags_lds + 4u * (unsigned)pslot, vals_lds + (unsigned)sizeof(V) * (unsigned)pslot, vv, dprev.x);
                 if ((dprev.w >> 30) & 1) {
-                    const unsigned sd = (unsigned)(dprev.x & (SW_LEVEL_SIDE - 1)), ps = (unsigned)(nslot + 1) + sd;
+                    const unsigned sd = (unsigned)((pb_prev + tid) & (SW_LEVEL_SIDE - 1)), ps = (unsigned)(nslot + 1) + sd;
                     if (lds_claim(lock_lds + 4u * sd, 2 * lv + 1)) ring_write<CB>(tags_lds + 4u * ps, vals_lds + (unsigned)sizeof(V) * ps, vv, dprev.x);
                 }
             }
@@ -756,8 +778,8 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
                 if (!(dbg & 1)) *reinterpret_cast<V*>(Lcol + (size_t)(unsigned)d.x * rowb) = vv;
                 ring_write<CB>(tags_lds + 4u * (unsigned)slot, vals_lds + (unsigned)sizeof(V) * (unsigned)slot, vv, d.x);
                 if (__ballot((d.w >> 30) & 1)) {   // pinned: a child will look for this row slice after it has left the ring
-                    if ((d.w >> 30) & 1) {   // (a pinned event that loses its side slot to another one of this level: its child defers)
-                        const unsigned sd = (unsigned)(d.x & (SW_LEVEL_SIDE - 1)), ps = (unsigned)(nslot + 1) + sd;
+                    if ((d.w >> 30) & 1) {   // (more than SW_LEVEL_SIDE pinned events in one level: the later claimant's child defers)
+                        const unsigned sd = (unsigned)((pb_cur + tid) & (SW_LEVEL_SIDE - 1)), ps = (unsigned)(nslot + 1) + sd;   // (rank: pinned events head their level)
                         if (lds_claim(lock_lds + 4u * sd, 2 * lv + 2)) ring_write<CB>(tags_lds + 4u * ps, vals_lds + (unsigned)sizeof(V) * ps, vv, d.x);
                     }
                 }
@@ -770,10 +792,11 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
         s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn; t_nn = t_n3;
         dprev = d;
         d = dn;
+        pb_prev = pb_cur; pb_cur = pb_nxt;
         const int f = f_prev; f_prev = f_cur; f_cur = f_nxt; f_nxt = f;
     }
     if (stamp && (tid & 63) == 0)
-        for (int i = 0; i < 4; ++i) atomicAdd(&dbgp[8 + i], ph[i]);
+        for (int i = 0; i < 5; ++i) atomicAdd(&dbgp[8 + i], ph[i]);
 }
 
 template <int NW, int C, int F, int H, bool WIDE>

@@ -189,6 +189,7 @@ struct sw_ctx {
 
     // device: levels
     DBuf<int32_t> d_lev_cnt, d_lev_start, d_lev_cursor;
+    DBuf<int32_t> d_lev_cback, d_lev_pinbase, d_lev_pos;   // level sweep: the back cursors, pinned events in front of each level, descriptor position per event
     DBuf<uint8_t> d_lev_pin;     // level sweep: events whose row slice a child looks for after it has left the ring (k_level_hist)
     DBuf<int4> d_desc;
 
@@ -719,7 +720,7 @@ int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g, int64_t first_
         attr_set = true;
     }
     hipLaunchKernelGGL((k_cansee_stream<CB>), dim3(c->npad / CB), dim3(c->npad), g.lds, c->stream_cs,
-                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, nlev, c->d_L.p, c->npad, g.H, g.chs, (int)first_event, c->stream_dbg, c->d_flow_dbg);
+                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, (const int*)c->d_lev_pinbase.p, nlev, c->d_L.p, c->npad, g.H, g.chs, (int)first_event, c->stream_dbg, c->d_flow_dbg);
     return SW_OK;
 }
 
@@ -1368,6 +1369,9 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
         CHK(dgrow(c, c->d_lev_cursor, max_nlev, 0));
         CHK(dgrow(c, c->d_desc, max_k, 0));
         CHK(dgrow(c, c->d_lev_pin, max_k, 0));
+        CHK(dgrow(c, c->d_lev_pos, max_k, 0));
+        CHK(dgrow(c, c->d_lev_cback, max_nlev, 0));
+        CHK(dgrow(c, c->d_lev_pinbase, max_nlev + 1, 0));
     }
     while ((int)c->cs_events.size() < S) {
         hipEvent_t e;
@@ -1472,11 +1476,18 @@ int do_divide(sw_ctx* c, int64_t first, int64_t K) {
                                (const int*)c->d_cr.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (const int*)c->d_chain_start.p,
                                (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p, ringH, c->d_lev_pin.p);
             hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, cs, (const int*)c->d_lev_cnt.p, nlevs[i], c->d_lev_start.p, c->d_lev_cursor.p);
+            HIPCHK(c, hipMemsetAsync(c->d_lev_cback.p, 0, nlevs[i] * sizeof(int32_t), cs));
             hipLaunchKernelGGL(k_level_scatter, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (const int*)c->d_cr.p,
                                (const int*)c->d_sp.p, (const int*)c->d_op.p, (const int*)c->d_seq.p, (int)a, (int)k, hmins[i],
-                               (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_desc.p, ringH, np,
-                               (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p,
-                               (const unsigned char*)c->d_lev_pin.p);
+                               (const int*)c->d_lev_start.p, c->d_lev_cursor.p, c->d_lev_cback.p, c->d_desc.p, ringH, np,
+                               (const unsigned char*)c->d_lev_pin.p, c->d_lev_pos.p);
+            // pinned events in front of every level (the front cursors' exclusive scan), then the children's descriptors
+            hipLaunchKernelGGL(k_level_scan, dim3(1), dim3(1024), 0, cs, (const int*)c->d_lev_cursor.p, nlevs[i], c->d_lev_pinbase.p, c->d_lev_cback.p);
+            hipLaunchKernelGGL(k_level_patch, dim3(eb), dim3(256), 0, cs, (const int*)c->d_ht.p, (const int*)c->d_cr.p, (const int*)c->d_op.p,
+                               (const int*)c->d_seq.p, (int)a, (int)k, hmins[i], (const int*)c->d_lev_start.p, (const int*)c->d_lev_pinbase.p,
+                               c->d_desc.p, ringH, np, (const int*)c->d_chain_start.p, (const int*)c->d_chain_cnt.p, (const int*)c->d_chain_ev.p,
+                               (const int*)c->d_lev_pos.p);
+            c->ctr.kernel_launches += 2;
             c->ctr.kernel_launches += 3;
             scs = span_begin(c, cs);
             CHK(launch_cansee<NW>(c, nlevs[i], a));
@@ -2449,8 +2460,8 @@ int sw_destroy(sw_ctx* c) {
         u64 d[16] = {0};
         (void)hipMemcpy(d, c->d_flow_dbg, sizeof d, hipMemcpyDeviceToHost);
         if (d[11])
-            fprintf(stderr, "[sw] level sweep, workgroup 0 / wave 0, clocks per level over %llu levels: top + ring reads (+ deferred events) %.0f, compute + writes %.0f, barrier %.0f\n",
-                    d[11], (double)d[8] / d[11], (double)d[9] / d[11], (double)d[10] / d[11]);
+            fprintf(stderr, "[sw] level sweep, workgroup 0 / wave 0, clocks per level over %llu levels: top + ring reads (+ deferred events) %.0f, compute + writes %.0f, barrier %.0f; "
+                    "%llu levels with deferred events\n", d[11], (double)d[8] / d[11], (double)d[9] / d[11], (double)d[10] / d[11], d[12]);
         fprintf(stderr, "[sw] dataflow sweep, column 0: %llu events, %llu rows re-read from memory, %llu starved lane-trips, %llu wave-trips over %llu wave runs "
                 "(%.1f trips per wave run), loader passes %llu (+%llu idle)\n", d[0], d[1], d[2], d[3], d[6], d[6] ? (double)d[3] / (double)d[6] : 0.0, d[4], d[5]);
         (void)hipFree(c->d_flow_dbg);
@@ -2469,7 +2480,7 @@ int sw_destroy(sw_ctx* c) {
     dfree(c->d_cr); dfree(c->d_sp); dfree(c->d_op); dfree(c->d_ht); dfree(c->d_seq); dfree(c->d_round); dfree(c->d_L);
     dfree(c->d_chain_ev); dfree(c->d_coin); dfree(c->d_sig); dfree(c->d_t); dfree(c->d_S); dfree(c->d_finlist);
     if (c->d_fin) (void)hipFree(c->d_fin);
-    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start); dfree(c->d_lev_pin);
+    dfree(c->d_cdesc); dfree(c->d_bounds); dfree(c->d_cuts); dfree(c->d_chain_start); dfree(c->d_chain_cnt); dfree(c->d_chain_len); dfree(c->d_stake); dfree(c->d_lev_cnt); dfree(c->d_lev_start); dfree(c->d_lev_pin); dfree(c->d_lev_cback); dfree(c->d_lev_pinbase); dfree(c->d_lev_pos);
     dfree(c->d_lev_cursor); dfree(c->d_desc); dfree(c->d_lo); dfree(c->d_lopos); dfree(c->d_wit);
     dfree(c->d_fam); dfree(c->d_dec_call); dfree(c->d_dec_by); dfree(c->d_cons); dfree(c->d_newc); dfree(c->d_Sw); dfree(c->d_evalround);
     dfree(c->d_evalpos); dfree(c->d_lo_r); dfree(c->d_cur); dfree(c->d_unres); dfree(c->d_lo_next);
