@@ -611,7 +611,7 @@ __device__ __forceinline__ void ring_write(unsigned tag_addr, unsigned val_addr,
 template <int CB>
 __global__ void __launch_bounds__(1024)
 k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start, const int* __restrict__ lev_pinbase, int nlev,
-                int* L, int npad, int H, int chs, int first_event, int dbg, u64* dbgp) {
+                int* L, int npad, int H, int chs, int first_event) {
     typedef typename RingVec<CB>::T V;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr int NS = 4;
@@ -623,7 +623,7 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     V* vals = (V*)(dstage + (size_t)NS * CH);                // [nall]
     int* tags = (int*)(vals + (size_t)nall);                 // [nall]
     int* side_lock = tags + (size_t)nall;                    // [SW_LEVEL_SIDE]: the last phase that wrote the side slot (lds_claim)
-    int* s_flag = side_lock + SW_LEVEL_SIDE;                 // [3]: some event of level lv was deferred (slot lv % 3); by byte address only
+    int* s_flag = side_lock + SW_LEVEL_SIDE;                 // [1]: 1 + the last level an event of which was deferred; by byte address only
     const int tid = threadIdx.x, BT = blockDim.x;
     const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);   // first event slot of this wave
     // XCD-aware column groups: workgroup b runs on XCD b % 8 (observed); give each XCD a
@@ -651,7 +651,7 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     none.x = -1; none.y = -1;
     if constexpr (CB == 4) { none.z = -1; none.w = -1; }
     for (int i = tid; i < nall; i += BT) { tags[i] = -1; vals[i] = none; }
-    if (tid < 3) s_flag[tid] = 0;
+    if (tid == 0) s_flag[0] = -1;
     for (int i = tid; i < SW_LEVEL_SIDE; i += BT) side_lock[i] = 0;
     // descriptor chunks 0 .. 2 resident, chunk 3 in flight
     for (int i = tid; i < 3 * CH; i += BT) dstage[i] = i < total ? desc[i] : make_int4(-1, -1, -1, 0);
@@ -667,13 +667,8 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
     int pb_prev = 0, pb_cur = lev_pinbase[0];   // pinned events of the sweep in front of levels lv - 1, lv (their first side-table ranks)
     int4 dprev = make_int4(-1, -1, -1, 0);   // my event of the previous level, kept for the case it was deferred
     bool deferred = false;
-    int f_prev = 2, f_cur = 0, f_nxt = 1;    // flag slots of levels lv - 1, lv, lv + 1 (lv % 3)
-    const bool stamp = dbgp != nullptr && blockIdx.x == 0 && wave0 == 0;
-    u64 ph[5] = {0, 0, 0, 0, 0};
     // levels 0 .. nlev - 1, then one empty level that serves the deferred events of the last one
     for (int lv = 0; lv <= nlev; ++lv) {
-        u64 c0 = 0, c1 = 0, c2 = 0;
-        if (stamp) c0 = clock64();
         const int t_n3 = lv + 4 <= nlev ? lev_start[lv + 4] : t_nn;   // (end of level lv + 3: the next iteration's t_nn)
         const int pb_nxt = lev_pinbase[lv + 1 <= nlev ? lv + 1 : nlev];
         const int n_cur = t_cur - s_cur;   // events in this level (uniform)
@@ -690,7 +685,6 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
             issue_chunk(pend_q);
             n_since = 0;
         }
-        if (tid == 0) lds_set(flag_lds + 4u * (unsigned)f_nxt, 0);   // (level lv - 2's flag: read by everybody before the last barrier, raised again behind this level's)
         const bool mine = wave0 < n_cur;   // (scalar) some event of the level falls to this wave
         const int slot = d.w & 0x3fff;
         const int ib = (d.w >> 14) & 0x7fff;
@@ -698,14 +692,15 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
         int ta = 0, tb1 = 0, tb2 = 0, fl;
         V va = none, vb = none;
         if (mine) ring_read_parents<CB>(tags_lds + 4u * (unsigned)ia, vals_lds + (unsigned)sizeof(V) * (unsigned)ia, tags_lds + 4u * (unsigned)ib,
-                                        vals_lds + (unsigned)sizeof(V) * (unsigned)ib, flag_lds + 4u * (unsigned)f_prev, ta, va, tb1, vb, tb2, fl);
-        else fl = lds_get(flag_lds + 4u * (unsigned)f_prev);
-        if (__builtin_amdgcn_readfirstlane(fl)) {
+                                        vals_lds + (unsigned)sizeof(V) * (unsigned)ib, flag_lds, ta, va, tb1, vb, tb2, fl);
+        else fl = lds_get(flag_lds);
+        // (the flag word only grows; it equals lv iff level lv - 1 raised it, and then no wave gets past the meetings below — to
+        // where this level could raise it — before every wave has read it)
+        if (__builtin_amdgcn_readfirstlane(fl) == lv) {
             // rare: events of level lv - 1 were deferred.  Every wave drains its stores, then the deferred events take
             // both parents from L2 (their rows were stored before this point, by whichever wave), then the ring is read again.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
-            if (stamp) ph[4] += 1;
             if (deferred) {
                 int pa[CB], pb[CB], v[CB];
                 load_cols_sc1_and_wait<CB>(reinterpret_cast<const int*>(Lcol + (size_t)(unsigned)dprev.y * rowb), pa);
@@ -717,7 +712,7 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
                     const int t = pa[c] > pb[c] ? pa[c] : pb[c];
                     v[c] = (rel >= c * H && rel < (c + 1) * H) ? dprev.x : t;   // own entry (swirld.py:220)
                 }
-                if (!(dbg & 1)) store_cols<CB>(reinterpret_cast<int*>(Lcol + (size_t)(unsigned)dprev.x * rowb), v);
+                store_cols<CB>(reinterpret_cast<int*>(Lcol + (size_t)(unsigned)dprev.x * rowb), v);
                 V vv;
                 vv.x = v[0]; vv.y = v[1];
                 if constexpr (CB == 4) { vv.z = v[2]; vv.w = v[3]; }
@@ -730,9 +725,8 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
             n_since = 0;   // (the drain: nothing of mine is outstanding but these stores)
             lds_barrier();
             if (mine) ring_read_parents<CB>(tags_lds + 4u * (unsigned)ia, vals_lds + (unsigned)sizeof(V) * (unsigned)ia, tags_lds + 4u * (unsigned)ib,
-                                            vals_lds + (unsigned)sizeof(V) * (unsigned)ib, flag_lds + 4u * (unsigned)f_prev, ta, va, tb1, vb, tb2, fl);
+                                            vals_lds + (unsigned)sizeof(V) * (unsigned)ib, flag_lds, ta, va, tb1, vb, tb2, fl);
         }
-        if (stamp) c1 = clock64();
         int4 dn = make_int4(-1, -1, -1, 0);
         if (wave0 < n_nxt && t_cur + tid < t_nxt) dn = dstage[(t_cur + tid) & smask];
         deferred = false;
@@ -757,9 +751,8 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
                 n_since = 0;   // (the loads wait for everything of this wave)
             }
             bool hit = !(ma | mb);
-            if (dbg & 2) hit = true;
             deferred = act & !hit;
-            if (deferred) lds_set(flag_lds + 4u * (unsigned)f_cur, 1);
+            if (deferred) lds_set(flag_lds, lv + 1);
             const bool go = act & hit;
             if (go) {
                 V vv;
@@ -775,7 +768,7 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
                         if (rel >= 3 * H && rel < 4 * H) vv.w = d.x;
                     }
                 }
-                if (!(dbg & 1)) *reinterpret_cast<V*>(Lcol + (size_t)(unsigned)d.x * rowb) = vv;
+                *reinterpret_cast<V*>(Lcol + (size_t)(unsigned)d.x * rowb) = vv;
                 ring_write<CB>(tags_lds + 4u * (unsigned)slot, vals_lds + (unsigned)sizeof(V) * (unsigned)slot, vv, d.x);
                 if (__ballot((d.w >> 30) & 1)) {   // pinned: a child will look for this row slice after it has left the ring
                     if ((d.w >> 30) & 1) {   // (more than SW_LEVEL_SIDE pinned events in one level: the later claimant's child defers)
@@ -786,17 +779,12 @@ k_cansee_stream(const int4* __restrict__ desc, const int* __restrict__ lev_start
             }
             n_since += __ballot(go) != 0 ? 1 : 0;   // (a store instruction with at least one lane has certainly been issued: a LOWER bound)
         }
-        if (stamp) c2 = clock64();
         lds_barrier();
-        if (stamp) { const u64 c3 = clock64(); ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += 1; }
         s_cur = t_cur; t_cur = t_nxt; t_nxt = t_nn; t_nn = t_n3;
         dprev = d;
         d = dn;
         pb_prev = pb_cur; pb_cur = pb_nxt;
-        const int f = f_prev; f_prev = f_cur; f_cur = f_nxt; f_nxt = f;
     }
-    if (stamp && (tid & 63) == 0)
-        for (int i = 0; i < 5; ++i) atomicAdd(&dbgp[8 + i], ph[i]);
 }
 
 template <int NW, int C, int F, int H, bool WIDE>

@@ -256,7 +256,6 @@ struct sw_ctx {
     int BATCH = 24;    // loop iterations between host checks
     int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers: k_cansee_chunks / k_cansee_flow); 2 / 3 = level-bucketed sweep (k_cansee_stream, 1024 / 256 threads: the default beyond 256 members)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
-    int stream_dbg = 0;   // SW_STREAM_DBG (measurement only, WRONG results): 1 = the level sweep stores no rows, 2 = it takes ring misses for hits, 4 = it stores into 64 MB
     int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced, one wave per slot (unit stake only), 2 = bit-sliced two-level search (k_tally_tree)
     bool tally_auto = true;   // SW_TALLY_IMPL not set: large calls of ~256-member hashgraphs without strongly skewed activity use 2
@@ -720,7 +719,7 @@ int launch_cansee_stream(sw_ctx* c, int nlev, const CanseeCfg& g, int64_t first_
         attr_set = true;
     }
     hipLaunchKernelGGL((k_cansee_stream<CB>), dim3(c->npad / CB), dim3(c->npad), g.lds, c->stream_cs,
-                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, (const int*)c->d_lev_pinbase.p, nlev, c->d_L.p, c->npad, g.H, g.chs, (int)first_event, c->stream_dbg, c->d_flow_dbg);
+                       (const int4*)c->d_desc.p, (const int*)c->d_lev_start.p, (const int*)c->d_lev_pinbase.p, nlev, c->d_L.p, c->npad, g.H, g.chs, (int)first_event);
     return SW_OK;
 }
 
@@ -2316,7 +2315,6 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     if (c->elect_cg != 64 && c->elect_cg != 128 && c->elect_cg != 256) knob_err = "SW_ELECT_CG: 64, 128 or 256";
     knob("SW_GALLOP", 0, 255, &c->gallop_after);
     knob("SW_SKIP", 0, 32, &c->skip);
-    knob("SW_STREAM_DBG", 0, 7, &c->stream_dbg);
     knob("SW_RING_H", 0, 64, &c->ring_H_req);      // ring depth of the level-bucketed sweep (0 = automatic)
     if (!knob_err.empty()) {
         delete c;
@@ -2324,8 +2322,8 @@ int sw_create(int n_members, const uint64_t* stake, int coin_period, int device,
     }
     c->debug_timing = getenv("SW_DEBUG_TIMING") != nullptr;
     if (c->debug_timing) {
-        if (hipMalloc(&c->d_flow_dbg, 16 * sizeof(u64)) != hipSuccess) c->d_flow_dbg = nullptr;
-        else (void)hipMemset(c->d_flow_dbg, 0, 16 * sizeof(u64));
+        if (hipMalloc(&c->d_flow_dbg, 8 * sizeof(u64)) != hipSuccess) c->d_flow_dbg = nullptr;
+        else (void)hipMemset(c->d_flow_dbg, 0, 8 * sizeof(u64));
     }
     if (getenv("SW_DEBUG_CLOCKS")) {  // diagnostics: phase stamps of the round-loop kernels
         c->dbg_minor = atoi(getenv("SW_DEBUG_CLOCKS")) >= 2 ? 0 : 1;
@@ -2457,11 +2455,8 @@ int sw_destroy(sw_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->debug_timing && c->d_flow_dbg) {
-        u64 d[16] = {0};
+        u64 d[8] = {0};
         (void)hipMemcpy(d, c->d_flow_dbg, sizeof d, hipMemcpyDeviceToHost);
-        if (d[11])
-            fprintf(stderr, "[sw] level sweep, workgroup 0 / wave 0, clocks per level over %llu levels: top + ring reads (+ deferred events) %.0f, compute + writes %.0f, barrier %.0f; "
-                    "%llu levels with deferred events\n", d[11], (double)d[8] / d[11], (double)d[9] / d[11], (double)d[10] / d[11], d[12]);
         fprintf(stderr, "[sw] dataflow sweep, column 0: %llu events, %llu rows re-read from memory, %llu starved lane-trips, %llu wave-trips over %llu wave runs "
                 "(%.1f trips per wave run), loader passes %llu (+%llu idle)\n", d[0], d[1], d[2], d[3], d[6], d[6] ? (double)d[3] / (double)d[6] : 0.0, d[4], d[5]);
         (void)hipFree(c->d_flow_dbg);
