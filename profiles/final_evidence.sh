@@ -21,6 +21,9 @@ cp $OUT/traffic.json profiles/traffic.json    # (bench.py below quotes it)
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --members 1024 --events 2000000 --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --concurrent 0 --emulate-parts 2 > $OUT/bench_1024x2M_split2.json 2> $OUT/bench_1024x2M_split2.err
 python bench.py --members 64 --events 100000 --cpu-sample 0 > $OUT/bench_64x100k.json 2> $OUT/bench_64x100k.err
+python bench.py --members 1024 --events 2000000 --mode 2 --p0 0.4 --p1 0.02 --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 --concurrent 0 > $OUT/bench_1024x2M_coin_stress.json 2> $OUT/bench_1024x2M_coin_stress.err
+# configs[4]'s size on ONE GPU (205 GB of can_see table: one context)
+timeout 900 python bench.py --members 1024 --events 50000000 --mode 2 --p0 0.4 --p1 0.02 --steps 2 --warmup 0 --cpu-sample 0 --e2e-steps 0 --concurrent 0 --contexts 1 > $OUT/bench_c5_1024x50M.json 2> $OUT/bench_c5_1024x50M.err
 # 4. find_order: laps, timeline, counters
 ORDER_CALLS=12 python profiles/order_laps.py > $OUT/order_laps_256x1M.txt 2>&1
 rocprofv3 --kernel-trace -d $OUT/okt -o kt -- python profiles/order_laps.py > $OUT/okt.log 2>&1

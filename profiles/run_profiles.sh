@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w
 TJ=${TRAFFIC_JSON:-$OUT/traffic.json}
 python profiles/collect_traffic.py --stats $OUT/kernel_stats.txt $OUT/fetch $OUT/write $TJ "$COMMIT" "${TRAFFIC_KEY:-256x1000000x0}" "bench.py $PMCARGS" \
     k_cansee_chunks k_cansee_fixup k_cansee_flow k_cansee_stream k_resolve_band k_tally_bits k_tally_tree k_elections k_voter_masks_bits k_finalize_events k_finalize_check k_finalize_listed \
-    k_order_walk k_order_median k_order_sort k_order_bounds > $OUT/traffic.log 2>&1
+    k_order_walk k_order_median k_order_sort k_order_bounds k_level_hist k_level_scatter k_level_patch > $OUT/traffic.log 2>&1
 # 3. wave / wait / cache counters
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS \
     --output-format csv -d $OUT/pmc1 -o p1 -- python bench.py $PMCARGS > $OUT/pmc1.log 2>&1

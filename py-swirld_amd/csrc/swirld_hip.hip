@@ -254,7 +254,7 @@ struct sw_ctx {
     int MCAP = 0;      // largest band (events) the mask table can hold
     int NEARCAP = 0;   // band cap at round entry (doubles up to MCAP when a far candidate needs a tally)
     int BATCH = 24;    // loop iterations between host checks
-    int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers: k_cansee_chunks / k_cansee_flow); 2 / 3 = level-bucketed sweep (k_cansee_stream, 1024 / 256 threads: the default beyond 256 members)
+    int cansee_impl = 6;  // 6 = dataflow sweep (no levels, no barriers: k_cansee_chunks / k_cansee_flow); 2 / 3 = level-bucketed sweep (k_cansee_stream: the default beyond 256 members; one kernel since round 6, both values select it)
     int ring_H_req = 0;   // SW_RING_H override (0 = automatic)
     int flow_cfg = 1;     // SW_FLOW_CFG: FIFO / ring depths of the dataflow sweep: 0 = 16/32, 1 = 8/16, 2 = 16/16, 3 = 8/32
     int tally_impl = 1;   // 0 = column-lane tally, 1 = bit-sliced, one wave per slot (unit stake only), 2 = bit-sliced two-level search (k_tally_tree)
