@@ -318,6 +318,13 @@ int sw_reset(sw_ctx* ctx);
  */
 int sw_set_window(sw_ctx* ctx, int enable, int chunk_mb);
 int sw_get_window(sw_ctx* ctx, int64_t* first_resident_event, int64_t* resident_bytes, int64_t* evictions);
+/* A silent member pins the window at its last event: its latest row is the self-parent of its next event, and
+ * its front round keeps that round's thresholds in play (the reference keeps every row: swirld.py:69-72).
+ * sw_set_window_lapse(ctx, events > 0) — windowed mode only, default 0 = never — lets a member LAPSE once it
+ * has been silent for more than `events` events: it stops holding the window back, and in exchange its further
+ * events are refused with SW_ERANGE (so are, as before, events whose other-parent row was evicted) until
+ * sw_rewind / sw_reset.  Results for every accepted event stay those of the reference. */
+int sw_set_window_lapse(sw_ctx* ctx, int64_t events);
 
 /*
  * Forked hashgraphs (swirld.py:170-184 height-based maxi, :221-222 witness overwrite, README.md:84).

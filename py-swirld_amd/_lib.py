@@ -85,6 +85,7 @@ SIGNATURES = {
     "sw_get_witness_order": (C.c_int, [_P, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "sw_set_window": (C.c_int, [_P, C.c_int, C.c_int]),
     "sw_get_window": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sw_set_window_lapse": (C.c_int, [_P, C.c_int64]),
     "sw_rewind": (C.c_int, [_P]),
     "sw_reset": (C.c_int, [_P]),
     "sw_synchronize": (C.c_int, [_P]),

@@ -101,6 +101,8 @@ struct sw_ctx {
     int split_emulate = 0;         // SW_SPLIT_EMULATE (measurement): this many parts played by this one context, one behind the other
     VmTable vm;
     int64_t first_resident = 0;   // can_see rows below this event index have been evicted (windowed mode)
+    int64_t window_lapse = 0;     // sw_set_window_lapse: a member silent for more than this many events no longer holds the window back (0 = never)
+    std::vector<char> lapsed;     // ... and is marked here: its further events are refused (SW_ERANGE) until a rewind / reset
     bool vm_scratch_ok = false;   // windowed mode: the halo scratch rows behind row `cap` are mapped (the sweep may run in chunks)
     DBuf<int32_t> d_ordpos;       // per member: chain positions already ordered (find_order's search bound)
     // exact path for forked hashgraphs (exact.hip.h): entered at the first forked event, left by sw_reset
@@ -1827,7 +1829,19 @@ int window_evict(sw_ctx* c) {
     int64_t horizon = c->N;
     int fmin = 0x7fffffff;
     CHK(ensure_pool_h(c));
+    // members that have LAPSED (sw_set_window_lapse; the reference has no such notion: it keeps every row): silent for more
+    // than `window_lapse` events.  Their latest row, their unordered tail and their front round stop holding the window
+    // back; in exchange their further events are refused — waking one would restart the round loop at its old front
+    // round, whose band begins at thresholds long evicted.  No other path reads their old rows: a round's band and
+    // tally only follow members with a witness in it, find_order only chains with a famous witness in the rounds it orders.
+    if (c->window_lapse > 0) {
+        if ((int)c->lapsed.size() != n) c->lapsed.assign(n, 0);
+        for (int m = 0; m < n; ++m)
+            if (c->head[m] >= 0 && (int64_t)c->head[m] < c->N - c->window_lapse) c->lapsed[m] = 1;
+    }
+    auto is_lapsed = [&](int m) { return c->window_lapse > 0 && c->lapsed[m]; };
     for (int m = 0; m < n; ++m) {
+        if (is_lapsed(m)) continue;
         if (c->head[m] >= 0) horizon = std::min<int64_t>(horizon, c->head[m]);
         if (c->ord_pos[m] < c->nev[m]) horizon = std::min<int64_t>(horizon, c->chain_ev_h[(size_t)c->chain_start_h[m] + c->ord_pos[m]]);
         if (c->front[m] >= 0) fmin = std::min(fmin, c->front[m]);
@@ -1837,7 +1851,7 @@ int window_evict(sw_ctx* c) {
         std::vector<int32_t> row(np);
         HIPCHK(c, hipMemcpyAsync(row.data(), c->d_lo.p + (size_t)rmin * np, np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int m = 0; m < n; ++m) if (row[m] != SW_INF) horizon = std::min<int64_t>(horizon, row[m]);
+        for (int m = 0; m < n; ++m) if (row[m] != SW_INF && !is_lapsed(m)) horizon = std::min<int64_t>(horizon, row[m]);
     } else horizon = 0;
     const size_t rowbytes = (size_t)np * sizeof(int32_t);
     CHK(vm_evict_below(c, (size_t)std::max<int64_t>(horizon, 0) * rowbytes));
@@ -2203,7 +2217,7 @@ int do_find_order(sw_ctx* c, std::vector<int32_t> rounds, int32_t* out_events, i
 // ====================================================================================
 extern "C" {
 
-int sw_version(void) { return 6; }
+int sw_version(void) { return 7; }
 
 const char* sw_last_error(const sw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -2917,6 +2931,9 @@ int sw_append_events(sw_ctx* c, int64_t K, const int32_t* creator, const int32_t
         if (m < 0 || m >= n) return fail(c, SW_EINVAL, "event %lld: creator %d out of range", (long long)e, m);
         if ((s < 0) != (o < 0)) return fail(c, SW_EINVAL, "event %lld: must have 0 or 2 parents", (long long)e);
         if (s >= e || o >= e) return fail(c, SW_EINVAL, "event %lld: parent index not earlier (not a topological order)", (long long)e);
+        if (!c->lapsed.empty() && c->lapsed[m])
+            return fail(c, SW_ERANGE, "event %lld: member %d was silent for more than %lld events and has lapsed out of the windowed table (sw_set_window_lapse)",
+                        (long long)e, m, (long long)c->window_lapse);
         if (s >= 0 && (s < c->first_resident || o < c->first_resident))
             return fail(c, SW_ERANGE, "event %lld: the can_see row of a parent was evicted (windowed mode keeps rows from event %lld on)", (long long)e, (long long)c->first_resident);
         if (head_t[m] != s) {
@@ -3343,6 +3360,15 @@ int sw_set_window(sw_ctx* c, int enable, int chunk_mb) {
     return SW_OK;
 }
 
+int sw_set_window_lapse(sw_ctx* c, int64_t events) {
+    if (!c) return SW_EINVAL;
+    if (events < 0) return fail(c, SW_EINVAL, "sw_set_window_lapse: a number of events >= 0 (0 = members never lapse)");
+    if (!c->vm.active && events > 0) return fail(c, SW_EINVAL, "sw_set_window_lapse needs the windowed table (sw_set_window first)");
+    c->window_lapse = events;
+    if (events == 0) c->lapsed.clear();
+    return SW_OK;
+}
+
 int sw_get_window(sw_ctx* c, int64_t* first_resident_event, int64_t* resident_bytes, int64_t* evictions) {
     if (!c) return SW_EINVAL;
     if (first_resident_event) *first_resident_event = c->first_resident;
@@ -3434,6 +3460,7 @@ int sw_rewind(sw_ctx* c) {
     }
     std::fill(c->front.begin(), c->front.end(), -1);
     std::fill(c->divided_cnt.begin(), c->divided_cnt.end(), 0);
+    std::fill(c->lapsed.begin(), c->lapsed.end(), 0);   // (every row is mapped again below: nobody has lapsed)
     if (c->vm.active && c->vm.lo > 0) {
         // every row is recomputed from event 0: the whole table moves to a fresh reservation (made before
         // the old one is given back, so the addresses differ), physical chunks recycled through the pool

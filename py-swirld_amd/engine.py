@@ -305,10 +305,14 @@ class Hashgraph:
         self._chk(self._L.sw_get_exact(self._h, C.byref(v)))
         return bool(v.value)
 
-    def set_window(self, enable=True, chunk_mb=0):
+    def set_window(self, enable=True, chunk_mb=0, lapse_events=0):
         """Windowed can_see table (before the first append): rows no later call can read are evicted
-        after every find_order (HIP virtual memory management, include/swirld_hip.h)."""
+        after every find_order (HIP virtual memory management, include/swirld_hip.h).  lapse_events > 0:
+        a member silent for more than that many events stops holding the window back and its further
+        events are refused (sw_set_window_lapse; the reference keeps every row)."""
         self._chk(self._L.sw_set_window(self._h, 1 if enable else 0, int(chunk_mb)))
+        if enable and lapse_events:
+            self._chk(self._L.sw_set_window_lapse(self._h, int(lapse_events)))
 
     def window(self):
         """(first resident event, bytes of the can_see table currently mapped, evictions so far)."""

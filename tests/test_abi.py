@@ -27,7 +27,7 @@ def test_header_symbols_exported(pkg):
     import importlib
     L = importlib.import_module("py-swirld_amd._lib")
     assert sorted(L.SIGNATURES) == syms, "ctypes table out of sync with the header"
-    assert lib.sw_version() == 6
+    assert lib.sw_version() == 7
 
 
 def test_integration_stub_matches_the_abi(pkg):

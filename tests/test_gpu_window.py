@@ -105,3 +105,88 @@ def test_window_off_after_reserve_keeps_the_halo_scratch_rows(pkg, monkeypatch):
     assert np.array_equal(h.rounds(), o.round)
     assert np.array_equal(h.can_see(N - 3000, 3000), o.can_see[N - 3000:])
     h.close()
+
+
+def gossip_with_a_silent_member(n, N, seed, silent, quiet_from):
+    """Uniform random gossip (every event: a random member syncs from another one's latest event) in which member
+    `silent` stops for good at event `quiet_from`: nobody creates for it or syncs from it afterwards."""
+    rng = np.random.default_rng(seed)
+    cr = np.empty(N, np.int32); sp = np.empty(N, np.int32); op = np.empty(N, np.int32)
+    head = np.full(n, -1, np.int64)
+    for m in range(n):                       # roots
+        cr[m], sp[m], op[m] = m, -1, -1
+        head[m] = m
+    for e in range(n, N):
+        while True:
+            a, b = (int(x) for x in rng.integers(0, n, 2))
+            if a != b and not (e >= quiet_from and silent in (a, b)):
+                break
+        cr[e], sp[e], op[e] = a, head[a], head[b]
+        head[a] = e
+    t = np.cumsum(rng.random(N)) + 1.0
+    sig = rng.integers(0, 256, (N, 64), dtype=np.uint8)
+    return cr, sp, op, t, sig, int(head[silent])
+
+
+def test_a_silent_member_lapses_and_the_window_moves_on(pkg):
+    """Without a lapse one silent member pins the window at its last event (the reference keeps every row anyway);
+    with sw_set_window_lapse the resident part stays bounded, every result equals the oracle's, and the lapsed member's
+    next event — as an event on top of any evicted row — is refused without a trace."""
+    from oracle.oracle import Oracle
+    n, N, chunk, silent, quiet_from = 48, 260_000, 10_000, 7, 30_000
+    cr, sp, op, t, sig, last = gossip_with_a_silent_member(n, N, 11, silent, quiet_from)
+    rowbytes = 64 * 4
+    residents = {}
+    for lapse in (0, 40_000):
+        o, h = Oracle(n), pkg.Hashgraph(n)
+        h.set_window(True, chunk_mb=2, lapse_events=lapse)
+        peak_late = 0
+        for a in range(0, N, chunk):
+            b = min(N, a + chunk)
+            for d in (o, h):
+                d.append_events(cr[a:b], sp[a:b], op[a:b], t[a:b], sig[a:b])
+                d.divide_rounds(a, b - a)
+            nco, nch = list(o.decide_fame()), list(h.decide_fame())
+            assert nco == nch
+            assert list(h.find_order(nch)) == list(o.find_order(nco))
+            if a >= N // 2:
+                peak_late = max(peak_late, h.window()[1])
+        assert np.array_equal(h.rounds(), o.round)
+        wit = h.witnesses()
+        assert np.array_equal(wit, o.witnesses())
+        m = wit >= 0
+        assert np.array_equal(h.famous()[m], o.famous_by_event[wit[m]])
+        assert np.array_equal(h.transactions(), o.transactions)
+        first, resident, evictions = h.window()
+        assert np.array_equal(h.can_see(first, N - first), o.can_see[first:])
+        residents[lapse] = (first, peak_late)
+        if lapse:
+            assert first > last + 100_000, "the window moved past the silent member's last event (%d): first resident event %d" % (last, first)
+            assert peak_late < 80_000 * rowbytes, "resident bytes stay bounded: %d" % peak_late
+            with pytest.raises(pkg.SwirldHipError) as ei:      # the lapsed member wakes up: refused, nothing stored
+                h.append_events([silent], [last], [N - 1])
+            assert ei.value.code == -34 and h.num_events == N and "lapsed" in str(ei.value)
+            with pytest.raises(pkg.SwirldHipError) as ei:      # somebody syncs from its (evicted) last event
+                h.append_events([int(cr[N - 1])], [N - 1], [last])
+            assert ei.value.code == -34 and h.num_events == N
+            # a rewind maps every row again and forgets who had lapsed
+            h.rewind()
+            h.divide_rounds(0, N)
+            h.decide_fame()
+            assert np.array_equal(h.rounds(), o.round)
+            e_new = N
+            h.append_events([silent], [last], [N - 1])
+            assert h.num_events == N + 1
+        else:
+            assert first <= last, "without a lapse the silent member's last event (%d) pins the window: first resident event %d" % (last, first)
+        h.close()
+    assert residents[40_000][1] < residents[0][1] // 2
+
+
+def test_window_lapse_needs_the_window(pkg):
+    h = pkg.Hashgraph(8)
+    with pytest.raises(pkg.SwirldHipError) as ei:
+        h._chk(h._L.sw_set_window_lapse(h._h, 1000))
+    assert ei.value.code == -22
+    h._chk(h._L.sw_set_window_lapse(h._h, 0))
+    h.close()
