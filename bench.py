@@ -459,6 +459,9 @@ def main():
     cs_impl = int(os.environ.get("SW_CANSEE_IMPL", "6" if npad <= 256 else "3"))
     cs_name = "k_cansee_flow" if cs_impl >= 6 else "k_cansee_stream"
     cs_note = "12n B per event (2 parent rows read, 1 written); bound by the dependency chain of the DAG (about 3.4 N/n levels)"
+    if cs_name == "k_cansee_stream":   # the level sweep: the parents' 8n B per event never leave LDS, only the row is written
+        cs_note = ("12n B per event algorithmic (2 parent rows read, 1 written); the parent rows come from per-member LDS rings, so 4n B per event "
+                   "cross the HBM interface; latency-bound on %d DAG levels (one LDS round trip + one barrier each)" % cd.get("levels", 0))
     if cd.get("chunk_sweeps", 0) > 0:  # the chunk-parallel sweep ran (k_cansee_chunks: the launch's span includes its gated repair kernels)
         cs_name = "k_cansee_chunks"
         cs_note = ("12n B per event (2 parent rows read, 1 written); %d chunks swept concurrently in %d launches, each from a halo of "
