@@ -50,6 +50,10 @@ def test_random_shapes(pkg, monkeypatch, seed):
             monkeypatch.setenv("SW_ORDER_S", str(int(org.choice([1, 3, 64]))))
         if org.random() < 0.25:
             monkeypatch.setenv(str(org.choice(["SW_ORDER_ONE_STREAM", "SW_ORDER_SORT_INLINE", "SW_ORDER_LATE_COPY"])), "1")
+    # (round 6) the level sweep's ring depth: shallow rings pin other-parents into its side table and defer events
+    lrg = np.random.default_rng(8500 + seed)
+    if lrg.random() < 0.6:
+        monkeypatch.setenv("SW_RING_H", str(int(lrg.choice([1, 1, 2, 4]))))
     stake = None
     if n >= 8 and rng.random() < 0.2:  # near-unit weighted stakes (the only weighted kind that progresses)
         stake = np.ones(n, np.uint64)
